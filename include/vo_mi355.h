@@ -1,0 +1,156 @@
+/*
+ * vo_mi355.h -- C ABI of libvo_mi355.so, the MI355X (gfx950) visual-odometry front-end.
+ *
+ * This is the drop-in boundary for the hot path of gilbertgonz/visual_slam
+ * (SURVEY.md section 8(b)).  The reference has no native FFI of its own: every entry point
+ * below replaces one cv2 call made from /root/reference/libs/vo_utils.py, and is what a
+ * ctypes binding inside that file would bind.
+ *
+ * Conventions: plain C, no exceptions cross the boundary.  Every function returns
+ * VO_OK (0) or a negative VO_ERR_* code; vo_last_error(ctx) gives the message of the
+ * last failure on that context.  The caller allocates every output with the capacity
+ * it passes in.  "host" pointers are ordinary process memory; "dev" pointers are HIP
+ * device memory on the context's GPU (e.g. torch.Tensor.data_ptr()).  One context per
+ * host thread / stream; calls on one context are serialised by the caller.
+ * There is NO CPU fallback: without a GPU vo_ctx_create fails.
+ */
+#ifndef VO_MI355_H
+#define VO_MI355_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VO_OK 0
+#define VO_ERR_INVALID (-1)     /* bad argument */
+#define VO_ERR_HIP (-2)         /* a HIP runtime call failed */
+#define VO_ERR_CAPACITY (-3)    /* an output or an internal list would overflow */
+#define VO_ERR_TOO_FEW (-4)     /* fewer than 5 matches / fewer than 2 train descriptors */
+#define VO_ERR_NO_MODEL (-5)    /* RANSAC found no essential matrix */
+
+typedef struct vo_ctx vo_ctx;
+
+/* cv2.ORB_create(3000) parameters, libs/vo_utils.py:23 (defaults = OpenCV's). */
+typedef struct {
+    int32_t nfeatures;      /* 3000 */
+    float   scale_factor;   /* 1.2f */
+    int32_t nlevels;        /* 8 (1..8 supported) */
+    int32_t edge_threshold; /* 31 (fixed) */
+    int32_t patch_size;     /* 31 (fixed) */
+    int32_t fast_threshold; /* 20 */
+    int32_t blur_mode;      /* 0: float sepFilter2D kernel (default), 1: int32 kernel x256 */
+    int32_t fma;            /* 1: fastAtan2 / float blur contract to fma (default), 0: not */
+} vo_orb_params;
+
+/* cv::KeyPoint without class_id (always -1). */
+typedef struct {
+    float x, y, size, angle, response;
+    int32_t octave;
+} vo_keypoint;
+
+/* One frame pair through get_matches + get_pose (libs/vo_utils.py:83-110,136-145). */
+typedef struct {
+    double  T[16];     /* form_transf(R, t), row-major 4x4 */
+    int32_t n_kp1;     /* keypoints in the previous frame (query) */
+    int32_t n_kp2;     /* keypoints in the current frame (train) */
+    int32_t n_match;   /* matches that pass the ratio test */
+    int32_t n_inlier;  /* RANSAC inliers of the returned E */
+    int32_t n_good;    /* recoverPose cheirality count */
+    int32_t status;    /* VO_OK or VO_ERR_* for this pair */
+} vo_pair_result;
+
+void vo_default_orb_params(vo_orb_params* p);
+
+/* Replaces VisualOdometry.__init__'s cv2 object construction (libs/vo_utils.py:23-33):
+ * creates the device context and its HBM workspace for images up to max_w x max_h.
+ * chunk_pairs: frame pairs whose detect+match stages run in one launch wave (the chunk's
+ * pyramids are sized to stay resident in the 256 MiB Infinity Cache; 2*chunk_pairs frames).
+ * max_pairs: frame pairs whose pose stage (RANSAC + recoverPose) runs in one launch wave. */
+int vo_ctx_create(int device, int max_w, int max_h, int chunk_pairs, int max_pairs,
+                  const vo_orb_params* params, vo_ctx** out);
+void vo_ctx_destroy(vo_ctx* ctx);
+const char* vo_last_error(const vo_ctx* ctx);
+
+/* Replaces orb.detectAndCompute(img, None), libs/vo_utils.py:94-95.
+ * img: host, 8-bit gray, h rows of `stride` bytes.  kps/desc: host, capacity `cap`
+ * keypoints (desc is [cap][32]).  *n receives the number of keypoints. */
+int vo_orb_detect_compute(vo_ctx* ctx, const uint8_t* img, int w, int h, int stride,
+                          vo_keypoint* kps, uint8_t* desc, int cap, int* n);
+
+/* Replaces knnMatch(f1, f2, k=2) + the ratio loop, libs/vo_utils.py:98-104, with the
+ * north-star's exact BFMatcher(NORM_HAMMING).  q,t: host [n][32].  Outputs (host, capacity
+ * cap): for each kept match, ascending queryIdx: queryIdx, trainIdx, best and second-best
+ * distance.  ratio is the Python double (0.45): keep iff (double)d1 < ratio*(double)d2. */
+int vo_match_knn2_ratio(vo_ctx* ctx, const uint8_t* q, int nq, const uint8_t* t, int nt, double ratio,
+                        int32_t* qidx, int32_t* tidx, int32_t* d1, int32_t* d2, int cap, int* n);
+
+/* Same matcher without the ratio filter: all nq rows (idx1,d1,idx2,d2), host arrays [nq]. */
+int vo_match_knn2(vo_ctx* ctx, const uint8_t* q, int nq, const uint8_t* t, int nt,
+                  int32_t* idx1, int32_t* d1, int32_t* idx2, int32_t* d2);
+
+/* Replaces cv2.findEssentialMat(q1, q2, K, cv2.RANSAC, prob, thr, maxIters),
+ * libs/vo_utils.py:141.  q1,q2: host float32 [n][2]; K row-major; E row-major; mask [n]. */
+int vo_find_essential_ransac(vo_ctx* ctx, const float* q1, const float* q2, int n, const double K[9],
+                             double prob, double thr, int max_iters,
+                             double E[9], uint8_t* mask, int* n_inliers);
+
+/* Replaces cv2.recoverPose(E, q1, q2, K, <R out>), libs/vo_utils.py:143: no input mask,
+ * distanceThresh 50 in the reference's call. */
+int vo_recover_pose(vo_ctx* ctx, const double E[9], const float* q1, const float* q2, int n, const double K[9],
+                    double dist_thresh, double R[9], double t[3], int* n_good);
+
+/* Replaces cv2.triangulatePoints(P1, P2, pts1, pts2), libs/vo_utils.py:160, batched over
+ * n points: x1,x2 host float32 [n][2]; X4 host float32 [4][n] (homogeneous, as cv2). */
+int vo_triangulate(vo_ctx* ctx, const double P1[12], const double P2[12], const float* x1, const float* x2,
+                   int n, float* X4);
+
+/* The whole per-pair path for a batch of B independent frame pairs whose images are
+ * already resident in device memory: imgsA/imgsB are dev pointers to [B][h][stride]
+ * uint8 (previous / current frames).  out: HOST array [B].  Detect+match run in chunks of
+ * chunk_pairs, the pose stage over up to max_pairs pairs at once.  stream: hipStream_t or NULL. */
+int vo_pairs_run_device(vo_ctx* ctx, const uint8_t* imgsA_dev, const uint8_t* imgsB_dev, int B,
+                        int w, int h, int stride, const double K[9], double ratio,
+                        vo_pair_result* out_host, void* stream);
+
+/* Same with host images (adds the H2D copy). */
+int vo_pairs_run(vo_ctx* ctx, const uint8_t* imgsA, const uint8_t* imgsB, int B,
+                 int w, int h, int stride, const double K[9], double ratio, vo_pair_result* out);
+
+/* Stage read-back for parity tests: copies an internal device buffer of the last
+ * vo_orb_detect_compute / vo_pairs_run* chunk to host.  `what`: see VO_DBG_*.
+ * Returns the number of bytes the buffer holds (copying at most `bytes`). */
+#define VO_DBG_PYR_LEVEL 1      /* frame, level -> tight level image (w_l*h_l bytes) */
+#define VO_DBG_BLUR_LEVEL 2     /* frame, level -> tight blurred level */
+#define VO_DBG_FAST_LIST 3      /* frame, level -> int32 [n][3] x,y,score (raster order) */
+#define VO_DBG_SEL1_LIST 4      /* frame, level -> int32 [n][3] after retainBest(2*quota) */
+#define VO_DBG_SEL1_HARRIS 5    /* frame, level -> float [n] Harris of the SEL1 list */
+#define VO_DBG_KEYPOINTS 6      /* frame -> vo_keypoint [n] */
+#define VO_DBG_DESCRIPTORS 7    /* frame -> uint8 [n][32] */
+#define VO_DBG_MATCHES 8        /* pair -> int32 [n][4] queryIdx, trainIdx, d1, d2 after ratio */
+#define VO_DBG_E_MASK 9         /* pair -> double E[9] followed by uint8 mask[n_match] */
+long vo_debug_read(vo_ctx* ctx, int what, int index, int level, void* out, long bytes);
+/* retainBest permutes its list in place, so the FAST and SEL1 lists only exist if the detect
+ * chain is stopped early: 0 = run everything (default), 1 = stop after the FAST lists,
+ * 2 = stop after retainBest #1 + Harris. */
+int vo_set_debug_stop(vo_ctx* ctx, int stage);
+
+/* Timing of the last vo_pairs_run_device call, measured with HIP events on the stream
+ * the kernels were launched on: stage_ms[VO_N_STAGES] and launches per stage.  Only
+ * collected when enabled (it adds event records between stages). */
+#define VO_N_STAGES 8
+#define VO_STAGE_PYRAMID 0
+#define VO_STAGE_FAST 1
+#define VO_STAGE_SELECT 2    /* both retainBest passes + Harris */
+#define VO_STAGE_ORIENT 3
+#define VO_STAGE_BLUR 4
+#define VO_STAGE_DESCRIBE 5
+#define VO_STAGE_MATCH 6
+#define VO_STAGE_POSE 7
+int vo_set_stage_timing(vo_ctx* ctx, int enable);
+int vo_get_stage_timing(vo_ctx* ctx, float stage_ms[VO_N_STAGES]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

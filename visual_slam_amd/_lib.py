@@ -1,0 +1,210 @@
+"""ctypes binding of libvo_mi355.so (include/vo_mi355.h).
+
+The library is the product; there is no CPU fallback.  If the shared object is missing
+or no GPU is present, the calls fail loudly.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "libvo_mi355.so")
+
+VO_OK, VO_ERR_INVALID, VO_ERR_HIP, VO_ERR_CAPACITY, VO_ERR_TOO_FEW, VO_ERR_NO_MODEL = 0, -1, -2, -3, -4, -5
+
+VO_DBG_PYR_LEVEL, VO_DBG_BLUR_LEVEL, VO_DBG_FAST_LIST, VO_DBG_SEL1_LIST, VO_DBG_SEL1_HARRIS = 1, 2, 3, 4, 5
+VO_DBG_KEYPOINTS, VO_DBG_DESCRIPTORS, VO_DBG_MATCHES, VO_DBG_E_MASK = 6, 7, 8, 9
+VO_N_STAGES = 8
+STAGE_NAMES = ["pyramid", "fast", "select", "orient", "blur", "describe", "match", "pose"]
+
+
+class OrbParams(C.Structure):
+    _fields_ = [
+        ("nfeatures", C.c_int32), ("scale_factor", C.c_float), ("nlevels", C.c_int32), ("edge_threshold", C.c_int32),
+        ("patch_size", C.c_int32), ("fast_threshold", C.c_int32), ("blur_mode", C.c_int32), ("fma", C.c_int32),
+    ]
+
+
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"), ("octave", "<i4")])
+PAIR_DTYPE = np.dtype([("T", "<f8", (4, 4)), ("n_kp1", "<i4"), ("n_kp2", "<i4"), ("n_match", "<i4"), ("n_inlier", "<i4"),
+                       ("n_good", "<i4"), ("status", "<i4")])
+
+# every symbol include/vo_mi355.h declares
+EXPORTS = [
+    "vo_default_orb_params", "vo_ctx_create", "vo_ctx_destroy", "vo_last_error", "vo_orb_detect_compute", "vo_match_knn2_ratio",
+    "vo_match_knn2", "vo_find_essential_ransac", "vo_recover_pose", "vo_triangulate", "vo_pairs_run_device", "vo_pairs_run",
+    "vo_debug_read", "vo_set_debug_stop", "vo_set_stage_timing", "vo_get_stage_timing",
+]
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise RuntimeError(
+            "libvo_mi355.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'`; "
+            "there is no CPU fallback." % SO_PATH)
+    lib = C.CDLL(SO_PATH)
+    vp, i, d = C.c_void_p, C.c_int, C.c_double
+    lib.vo_ctx_create.argtypes = [i, i, i, i, i, vp, C.POINTER(vp)]
+    lib.vo_ctx_destroy.argtypes = [vp]
+    lib.vo_ctx_destroy.restype = None
+    lib.vo_last_error.argtypes = [vp]
+    lib.vo_last_error.restype = C.c_char_p
+    lib.vo_orb_detect_compute.argtypes = [vp, vp, i, i, i, vp, vp, i, vp]
+    lib.vo_match_knn2_ratio.argtypes = [vp, vp, i, vp, i, d, vp, vp, vp, vp, i, vp]
+    lib.vo_match_knn2.argtypes = [vp, vp, i, vp, i, vp, vp, vp, vp]
+    lib.vo_find_essential_ransac.argtypes = [vp, vp, vp, i, vp, d, d, i, vp, vp, vp]
+    lib.vo_recover_pose.argtypes = [vp, vp, vp, vp, i, vp, d, vp, vp, vp]
+    lib.vo_triangulate.argtypes = [vp, vp, vp, vp, vp, i, vp]
+    lib.vo_pairs_run_device.argtypes = [vp, vp, vp, i, i, i, i, vp, d, vp, vp]
+    lib.vo_pairs_run.argtypes = [vp, vp, vp, i, i, i, i, vp, d, vp]
+    lib.vo_debug_read.argtypes = [vp, i, i, i, vp, C.c_long]
+    lib.vo_debug_read.restype = C.c_long
+    lib.vo_set_debug_stop.argtypes = [vp, i]
+    lib.vo_set_stage_timing.argtypes = [vp, i]
+    lib.vo_get_stage_timing.argtypes = [vp, vp]
+    _lib = lib
+    return lib
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class VoError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("libvo_mi355 error %d: %s" % (code, msg))
+        self.code = code
+
+
+class Context:
+    """One device context (one HIP stream, one workspace).  Not thread-safe."""
+
+    def __init__(self, max_w=1241, max_h=376, chunk_pairs=1, max_pairs=1, device=0, **orb):
+        self.lib = load()
+        self.params = OrbParams()
+        self.lib.vo_default_orb_params(C.byref(self.params))
+        for k, v in orb.items():
+            setattr(self.params, k, v)
+        h = C.c_void_p()
+        rc = self.lib.vo_ctx_create(device, max_w, max_h, chunk_pairs, max_pairs, C.byref(self.params), C.byref(h))
+        self.h = h
+        if rc != VO_OK:
+            msg = self.lib.vo_last_error(h).decode() if h else "allocation failed"
+            if h:
+                self.lib.vo_ctx_destroy(h)
+            self.h = None
+            raise VoError(rc, msg)
+        self.kp_cap = self.params.nfeatures + 1024
+        self.device = device
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.vo_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != VO_OK:
+            raise VoError(rc, self.lib.vo_last_error(self.h).decode())
+
+    # ---- cv2 call replacements (host arrays)
+    def orb_detect_compute(self, img):
+        img = np.ascontiguousarray(img, dtype=np.uint8)
+        if img.ndim != 2:
+            raise ValueError("expected a single-channel 8-bit image")
+        h, w = img.shape
+        kps = np.zeros(self.kp_cap, KP_DTYPE)
+        desc = np.zeros((self.kp_cap, 32), np.uint8)
+        n = C.c_int(0)
+        self._check(self.lib.vo_orb_detect_compute(self.h, _ptr(img), w, h, img.strides[0], _ptr(kps), _ptr(desc), self.kp_cap, C.byref(n)))
+        return kps[: n.value].copy(), desc[: n.value].copy()
+
+    def match_knn2(self, q, t):
+        q = np.ascontiguousarray(q, np.uint8).reshape(-1, 32)
+        t = np.ascontiguousarray(t, np.uint8).reshape(-1, 32)
+        out = [np.zeros(max(len(q), 1), np.int32) for _ in range(4)]
+        self._check(self.lib.vo_match_knn2(self.h, _ptr(q), len(q), _ptr(t), len(t), *[_ptr(o) for o in out]))
+        return tuple(o[: len(q)] for o in out)
+
+    def match_knn2_ratio(self, q, t, ratio=0.45):
+        q = np.ascontiguousarray(q, np.uint8).reshape(-1, 32)
+        t = np.ascontiguousarray(t, np.uint8).reshape(-1, 32)
+        cap = max(len(q), 1)
+        out = [np.zeros(cap, np.int32) for _ in range(4)]
+        n = C.c_int(0)
+        self._check(self.lib.vo_match_knn2_ratio(self.h, _ptr(q), len(q), _ptr(t), len(t), float(ratio), *[_ptr(o) for o in out], cap, C.byref(n)))
+        return tuple(o[: n.value].copy() for o in out)  # queryIdx, trainIdx, d1, d2
+
+    def find_essential_ransac(self, q1, q2, K, prob=0.999, thr=1.0, max_iters=1000):
+        q1 = np.ascontiguousarray(q1, np.float32).reshape(-1, 2)
+        q2 = np.ascontiguousarray(q2, np.float32).reshape(-1, 2)
+        K = np.ascontiguousarray(K, np.float64)
+        n = len(q1)
+        E = np.zeros((3, 3)); mask = np.zeros(max(n, 1), np.uint8); ninl = C.c_int(0)
+        self._check(self.lib.vo_find_essential_ransac(self.h, _ptr(q1), _ptr(q2), n, _ptr(K), prob, thr, max_iters, _ptr(E), _ptr(mask), C.byref(ninl)))
+        return E, mask[:n].copy(), ninl.value
+
+    def recover_pose(self, E, q1, q2, K, dist_thresh=50.0):
+        q1 = np.ascontiguousarray(q1, np.float32).reshape(-1, 2)
+        q2 = np.ascontiguousarray(q2, np.float32).reshape(-1, 2)
+        E = np.ascontiguousarray(E, np.float64); K = np.ascontiguousarray(K, np.float64)
+        R = np.zeros((3, 3)); t = np.zeros(3); ng = C.c_int(0)
+        self._check(self.lib.vo_recover_pose(self.h, _ptr(E), _ptr(q1), _ptr(q2), len(q1), _ptr(K), dist_thresh, _ptr(R), _ptr(t), C.byref(ng)))
+        return R, t, ng.value
+
+    def triangulate(self, P1, P2, x1, x2):
+        P1 = np.ascontiguousarray(P1, np.float64); P2 = np.ascontiguousarray(P2, np.float64)
+        x1 = np.ascontiguousarray(x1, np.float32).reshape(-1, 2); x2 = np.ascontiguousarray(x2, np.float32).reshape(-1, 2)
+        n = len(x1)
+        X4 = np.zeros((4, n), np.float32)
+        self._check(self.lib.vo_triangulate(self.h, _ptr(P1), _ptr(P2), _ptr(x1), _ptr(x2), n, _ptr(X4)))
+        return X4
+
+    # ---- batched pairs
+    def pairs_run(self, imgsA, imgsB, K, ratio=0.45):
+        imgsA = np.ascontiguousarray(imgsA, np.uint8); imgsB = np.ascontiguousarray(imgsB, np.uint8)
+        B, h, w = imgsA.shape
+        K = np.ascontiguousarray(K, np.float64)
+        out = np.zeros(B, PAIR_DTYPE)
+        self._check(self.lib.vo_pairs_run(self.h, _ptr(imgsA), _ptr(imgsB), B, w, h, w, _ptr(K), float(ratio), _ptr(out)))
+        return out
+
+    def pairs_run_device(self, ptrA, ptrB, B, w, h, stride, K, ratio=0.45, stream=None):
+        """ptrA/ptrB: device addresses (e.g. torch.Tensor.data_ptr()) of [B][h][stride] uint8."""
+        K = np.ascontiguousarray(K, np.float64)
+        out = np.zeros(B, PAIR_DTYPE)
+        self._check(self.lib.vo_pairs_run_device(self.h, C.c_void_p(ptrA), C.c_void_p(ptrB), B, w, h, stride, _ptr(K), float(ratio), _ptr(out),
+                                                 C.c_void_p(stream) if stream else None))
+        return out
+
+    # ---- diagnostics
+    def set_debug_stop(self, stage):
+        self._check(self.lib.vo_set_debug_stop(self.h, stage))
+
+    def set_stage_timing(self, enable):
+        self._check(self.lib.vo_set_stage_timing(self.h, int(enable)))
+
+    def stage_timing(self):
+        ms = np.zeros(VO_N_STAGES, np.float32)
+        self._check(self.lib.vo_get_stage_timing(self.h, _ptr(ms)))
+        return dict(zip(STAGE_NAMES, ms.tolist()))
+
+    def debug_read(self, what, index, level=0, dtype=np.uint8):
+        n = self.lib.vo_debug_read(self.h, what, index, level, None, 0)
+        if n < 0:
+            raise VoError(int(n), "vo_debug_read")
+        buf = np.zeros(max(int(n), 1), np.uint8)
+        if n:
+            self.lib.vo_debug_read(self.h, what, index, level, _ptr(buf), int(n))
+        return buf[: int(n)].view(dtype)

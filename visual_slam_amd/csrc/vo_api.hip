@@ -1,0 +1,520 @@
+// vo_api.hip -- context, workspace and the extern "C" entry points of libvo_mi355.so
+// (declared in include/vo_mi355.h; each stands behind one cv2 call of
+// /root/reference/libs/vo_utils.py).  No CPU fallback: every entry point runs HIP kernels.
+#include <algorithm>
+#include <cstring>
+
+#include "../../include/vo_orb_pattern_31.h"
+#include "vo_internal.h"
+
+int vo_fail(vo_ctx* c, int code, const std::string& msg) {
+    if (c) c->err = msg;
+    return code;
+}
+
+static int dev_alloc(vo_ctx* c, DevBuf& b, size_t bytes) {
+    bytes = std::max<size_t>(bytes, 256);
+    HIP_TRY(c, hipMalloc(&b.p, bytes));
+    b.bytes = bytes;
+    return VO_OK;
+}
+static void dev_free(DevBuf& b) {
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr;
+    b.bytes = 0;
+}
+#define ALLOC(c, buf, bytes)                         \
+    do {                                             \
+        int _rc = dev_alloc((c), (buf), (bytes));    \
+        if (_rc != VO_OK) return _rc;                \
+    } while (0)
+
+__global__ void k_results(const PoseWork* __restrict__ pw, const int* __restrict__ nmatch, const int2* __restrict__ pair_nkp, int P,
+                          vo_pair_result* __restrict__ out) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    const PoseWork& w = pw[p];
+    vo_pair_result r;
+    for (int i = 0; i < 16; i++) r.T[i] = 0;
+    if (w.status == VO_OK) {
+        for (int i = 0; i < 3; i++) {
+            for (int j = 0; j < 3; j++) r.T[i * 4 + j] = w.R[i * 3 + j];
+            r.T[i * 4 + 3] = w.t[i];
+        }
+        r.T[15] = 1;
+    }
+    r.n_kp1 = pair_nkp[p].x;
+    r.n_kp2 = pair_nkp[p].y;
+    r.n_match = nmatch[p];
+    r.n_inlier = w.max_good;
+    r.n_good = w.n_good;
+    r.status = w.status;
+    out[p] = r;
+}
+
+extern "C" {
+
+void vo_default_orb_params(vo_orb_params* p) {
+    p->nfeatures = 3000;  // libs/vo_utils.py:23
+    p->scale_factor = 1.2f;
+    p->nlevels = 8;
+    p->edge_threshold = 31;
+    p->patch_size = 31;
+    p->fast_threshold = 20;
+    p->blur_mode = 0;
+    p->fma = 1;
+}
+
+static int ctx_init(vo_ctx* c) {
+    const vo_orb_params& p = c->params;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    for (int i = 0; i <= VO_N_STAGES; i++) HIP_TRY(c, hipEventCreate(&c->ev[i]));
+    c->kp_cap = p.nfeatures + 1024;
+    const long F = c->max_frames, kc = c->kp_cap, MP = c->max_pairs, CP = c->chunk_pairs;
+    // geometry-sized buffers: size them for the largest image with a dry geometry pass
+    ALLOC(c, c->d_geom, sizeof(Geom));
+    // upper bounds from the max image size (all quantities are monotone in w, h)
+    const long W = c->max_w, H = c->max_h;
+    long pyr = 0, blur = 0, cand = 0, tiles = 0, segs = 0, btiles = 0, rt = 0;
+    {
+        const double sf = (double)p.scale_factor;
+        for (int l = 0; l < p.nlevels; l++) {
+            const float sc = (float)std::pow(sf, (double)l);
+            const long w = (long)nearbyintf(W * (1.f / sc)) + 1, h = (long)nearbyintf(H * (1.f / sc)) + 1;
+            const long pitch = (w + 63) / 64 * 64;
+            if (l > 0) pyr += (pitch * h + 255) / 256 * 256;
+            blur += (pitch * h + 255) / 256 * 256;
+            const long iw = std::max(w - 62, 0L), ih = std::max(h - 62, 0L);
+            const long ntx = (iw + 31) / 32, nty = (ih + 31) / 32;
+            tiles += ntx * nty;
+            segs += (ih * ntx + 15) / 16 * 16;
+            cand += (((iw + 1) / 2) * ((ih + 1) / 2) + 63) / 64 * 64;
+            btiles += ((w + 63) / 64) * ((h + 15) / 16);
+            rt += w + h;
+        }
+    }
+    ALLOC(c, c->d_tiles, (tiles + 1) * sizeof(TileDesc));
+    ALLOC(c, c->d_btiles, (btiles + 1) * sizeof(TileDesc));
+    ALLOC(c, c->d_rtab, (rt + 1) * sizeof(ResizeCoef));
+    ALLOC(c, c->d_img, (size_t)F * W * H);
+    ALLOC(c, c->d_pyr, (size_t)F * (pyr + 256));
+    ALLOC(c, c->d_blur, (size_t)F * (blur + 256));
+    ALLOC(c, c->d_tile_list, (size_t)F * tiles * VO_TILE_CAP * 4);
+    ALLOC(c, c->d_seg_cnt, (size_t)F * segs);
+    ALLOC(c, c->d_seg_ofs, (size_t)F * segs * 4);
+    ALLOC(c, c->d_key, (size_t)F * cand * 4);
+    ALLOC(c, c->d_payload, (size_t)F * cand * 4);
+    ALLOC(c, c->d_lpos, (size_t)F * cand * 4);
+    ALLOC(c, c->d_rpos, (size_t)F * cand * 4);
+    ALLOC(c, c->d_cnt_fast, (size_t)F * VO_MAX_LEVELS * 4);
+    ALLOC(c, c->d_cnt_sel1, (size_t)F * VO_MAX_LEVELS * 4);
+    ALLOC(c, c->d_cnt_sel2, (size_t)F * VO_MAX_LEVELS * 4);
+    ALLOC(c, c->d_nkp, (size_t)F * 4);
+    ALLOC(c, c->d_frame_status, (size_t)F * 4);
+    ALLOC(c, c->d_kp, (size_t)F * kc * sizeof(vo_keypoint));
+    ALLOC(c, c->d_kplvl, (size_t)F * kc * 4);
+    ALLOC(c, c->d_desc, (size_t)F * kc * 32);
+    ALLOC(c, c->d_match, (size_t)CP * 4 * kc * sizeof(uint2));
+    ALLOC(c, c->d_raw, (size_t)kc * sizeof(int4));
+    ALLOC(c, c->d_nmatch, (size_t)MP * 4);
+    ALLOC(c, c->d_pair_status, (size_t)MP * 4);
+    ALLOC(c, c->d_pair_nkp, (size_t)MP * 8);
+    ALLOC(c, c->d_mq, (size_t)MP * kc * sizeof(int4));
+    ALLOC(c, c->d_q1, (size_t)MP * kc * sizeof(float2));
+    ALLOC(c, c->d_q2, (size_t)MP * kc * sizeof(float2));
+    ALLOC(c, c->d_mask, (size_t)MP * kc);
+    ALLOC(c, c->d_pose, (size_t)MP * sizeof(PoseWork));
+    ALLOC(c, c->d_hyp, (size_t)MP * VO_HYP_ROUND * 90 * sizeof(double));
+    ALLOC(c, c->d_samples, (size_t)MP * VO_HYP_ROUND * 5 * 4);
+    ALLOC(c, c->d_nmodels, (size_t)MP * VO_HYP_ROUND * 4);
+    ALLOC(c, c->d_counts, (size_t)MP * VO_HYP_ROUND * 10 * 4);
+    ALLOC(c, c->d_vote, (size_t)MP * 4 * 4);
+    ALLOC(c, c->d_result, (size_t)MP * sizeof(vo_pair_result));
+    ALLOC(c, c->d_misc, 4096);
+    ALLOC(c, c->d_pat, 1024);
+    HIP_TRY(c, hipMemcpy(c->d_pat.p, VO_ORB_PATTERN_31, 1024, hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemset(c->d_frame_status.p, 0, c->d_frame_status.bytes));
+    HIP_TRY(c, hipMemset(c->d_pair_status.p, 0, c->d_pair_status.bytes));
+    HIP_TRY(c, hipMemset(c->d_kp.p, 0, c->d_kp.bytes));
+    return VO_OK;
+}
+
+int vo_ctx_create(int device, int max_w, int max_h, int chunk_pairs, int max_pairs, const vo_orb_params* params, vo_ctx** out) {
+    if (!out) return VO_ERR_INVALID;
+    *out = nullptr;
+    vo_ctx* c = new vo_ctx();
+    *out = c;  // returned even on failure so that vo_last_error() can be read; destroy it afterwards
+    c->device = device;
+    if (params) c->params = *params;
+    else vo_default_orb_params(&c->params);
+    const vo_orb_params& p = c->params;
+    if (max_w < 64 || max_h < 64 || max_w > 4095 || max_h > 4095 || chunk_pairs < 1 || max_pairs < 1 || chunk_pairs > 16384)
+        return vo_fail(c, VO_ERR_INVALID, "vo_ctx_create: size arguments out of range");
+    if (p.nlevels < 1 || p.nlevels > VO_MAX_LEVELS || p.patch_size != 31 || p.edge_threshold != 31 || p.nfeatures < 1 || p.nfeatures > 60000 ||
+        p.fast_threshold < 1 || p.fast_threshold > 254 || (p.blur_mode != 0 && p.blur_mode != 1))
+        return vo_fail(c, VO_ERR_INVALID, "vo_ctx_create: unsupported ORB parameters");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= device || device < 0)
+        return vo_fail(c, VO_ERR_HIP, "vo_ctx_create: no such HIP device (this library has no CPU fallback)");
+    c->max_w = max_w; c->max_h = max_h;
+    c->chunk_pairs = chunk_pairs;
+    c->max_pairs = std::max(max_pairs, chunk_pairs);
+    c->max_frames = 2 * chunk_pairs;
+    return ctx_init(c);
+}
+
+void vo_ctx_destroy(vo_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) { (void)hipStreamSynchronize(c->stream); }
+    DevBuf* bufs[] = {&c->d_geom, &c->d_tiles, &c->d_btiles, &c->d_rtab, &c->d_img, &c->d_pyr, &c->d_blur, &c->d_tile_list, &c->d_seg_cnt,
+                      &c->d_seg_ofs, &c->d_key, &c->d_payload, &c->d_lpos, &c->d_rpos, &c->d_cnt_fast, &c->d_cnt_sel1, &c->d_cnt_sel2, &c->d_nkp,
+                      &c->d_kp, &c->d_kplvl, &c->d_desc, &c->d_frame_status, &c->d_match, &c->d_nmatch, &c->d_mq, &c->d_q1, &c->d_q2, &c->d_pose,
+                      &c->d_hyp, &c->d_mask, &c->d_result, &c->d_misc, &c->d_pat, &c->d_pair_status, &c->d_samples, &c->d_nmodels, &c->d_counts,
+                      &c->d_vote, &c->d_pair_nkp, &c->d_raw, &c->d_tri};
+    for (DevBuf* b : bufs) dev_free(*b);
+    for (int i = 0; i <= VO_N_STAGES; i++)
+        if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char* vo_last_error(const vo_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+int vo_set_debug_stop(vo_ctx* c, int stage) {
+    if (!c || stage < 0 || stage > 2) return VO_ERR_INVALID;
+    c->debug_stop = stage;
+    return VO_OK;
+}
+
+int vo_set_stage_timing(vo_ctx* c, int enable) {
+    if (!c) return VO_ERR_INVALID;
+    c->timing = enable != 0;
+    return VO_OK;
+}
+int vo_get_stage_timing(vo_ctx* c, float stage_ms[VO_N_STAGES]) {
+    if (!c || !stage_ms) return VO_ERR_INVALID;
+    for (int i = 0; i < VO_N_STAGES; i++) stage_ms[i] = c->stage_ms[i];
+    return VO_OK;
+}
+
+// -------------------------------------------------------------------- detectAndCompute
+int vo_orb_detect_compute(vo_ctx* c, const uint8_t* img, int w, int h, int stride, vo_keypoint* kps, uint8_t* desc, int cap, int* n) {
+    if (!c) return VO_ERR_INVALID;
+    if (!img || !n || w <= 0 || h <= 0 || stride < w) return vo_fail(c, VO_ERR_INVALID, "vo_orb_detect_compute: bad arguments");
+    HIP_TRY(c, hipSetDevice(c->device));
+    int rc = vo_build_geometry(c, w, h);
+    if (rc != VO_OK) return rc;
+    hipStream_t st = c->stream;
+    HIP_TRY(c, hipMemcpy2DAsync(c->d_img.p, w, img, stride, w, h, hipMemcpyHostToDevice, st));
+    FrameSrc src{(const uint8_t*)c->d_img.p, (const uint8_t*)c->d_img.p, 1, w, (long)w * h};
+    c->last_src = src; c->last_frames = 1; c->last_pairs = 0;
+    rc = vo_launch_detect(c, src, 1, st);
+    if (rc != VO_OK) return rc;
+    int hn[2] = {0, 0};
+    HIP_TRY(c, hipMemcpyAsync(&hn[0], c->d_nkp.p, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipMemcpyAsync(&hn[1], c->d_frame_status.p, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipStreamSynchronize(st));
+    if (c->debug_stop) { *n = 0; return VO_OK; }
+    if (hn[1] != VO_OK) return vo_fail(c, hn[1], "vo_orb_detect_compute: keypoint list overflow (too many response ties)");
+    *n = hn[0];
+    if (hn[0] > cap) return vo_fail(c, VO_ERR_CAPACITY, "vo_orb_detect_compute: output capacity too small");
+    if (kps && hn[0]) HIP_TRY(c, hipMemcpy(kps, c->d_kp.p, (size_t)hn[0] * sizeof(vo_keypoint), hipMemcpyDeviceToHost));
+    if (desc && hn[0]) HIP_TRY(c, hipMemcpy(desc, c->d_desc.p, (size_t)hn[0] * 32, hipMemcpyDeviceToHost));
+    return VO_OK;
+}
+
+// -------------------------------------------------------------------- matcher
+static int match_host(vo_ctx* c, const uint8_t* q, int nq, const uint8_t* t, int nt, double ratio, bool want_raw) {
+    if (!q || !t || nq < 0 || nt < 0) return vo_fail(c, VO_ERR_INVALID, "matcher: bad arguments");
+    if (nq > c->kp_cap || nt > c->kp_cap) return vo_fail(c, VO_ERR_CAPACITY, "matcher: more descriptors than the context's keypoint capacity");
+    if (nt < 2) return vo_fail(c, VO_ERR_TOO_FEW, "knnMatch(k=2) needs at least 2 train descriptors");
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    const long kc = c->kp_cap;
+    int hn[2] = {nq, nt};
+    HIP_TRY(c, hipMemcpyAsync(c->d_nkp.p, hn, 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(c, hipMemsetAsync(c->d_frame_status.p, 0, 8, st));
+    if (nq) HIP_TRY(c, hipMemcpyAsync(c->d_desc.p, q, (size_t)nq * 32, hipMemcpyHostToDevice, st));
+    HIP_TRY(c, hipMemcpyAsync((uint8_t*)c->d_desc.p + kc * 32, t, (size_t)nt * 32, hipMemcpyHostToDevice, st));
+    c->last_pairs = 1;
+    int rc = vo_launch_match_impl(c, 1, 1, ratio, 0, want_raw ? (int4*)c->d_raw.p : nullptr, st);
+    if (rc != VO_OK) return rc;
+    HIP_TRY(c, hipStreamSynchronize(st));
+    return VO_OK;
+}
+
+int vo_match_knn2(vo_ctx* c, const uint8_t* q, int nq, const uint8_t* t, int nt, int32_t* idx1, int32_t* d1, int32_t* idx2, int32_t* d2) {
+    if (!c) return VO_ERR_INVALID;
+    int rc = match_host(c, q, nq, t, nt, 0.45, true);
+    if (rc != VO_OK) return rc;
+    std::vector<int4> raw(std::max(nq, 1));
+    if (nq) HIP_TRY(c, hipMemcpy(raw.data(), c->d_raw.p, (size_t)nq * sizeof(int4), hipMemcpyDeviceToHost));
+    for (int i = 0; i < nq; i++) {
+        if (idx1) idx1[i] = raw[i].x;
+        if (d1) d1[i] = raw[i].y;
+        if (idx2) idx2[i] = raw[i].z;
+        if (d2) d2[i] = raw[i].w;
+    }
+    return VO_OK;
+}
+
+int vo_match_knn2_ratio(vo_ctx* c, const uint8_t* q, int nq, const uint8_t* t, int nt, double ratio, int32_t* qidx, int32_t* tidx, int32_t* d1,
+                        int32_t* d2, int cap, int* n) {
+    if (!c) return VO_ERR_INVALID;
+    if (!n) return vo_fail(c, VO_ERR_INVALID, "vo_match_knn2_ratio: n is null");
+    int rc = match_host(c, q, nq, t, nt, ratio, false);
+    if (rc != VO_OK) return rc;
+    int nm = 0;
+    HIP_TRY(c, hipMemcpy(&nm, c->d_nmatch.p, 4, hipMemcpyDeviceToHost));
+    *n = nm;
+    if (nm > cap) return vo_fail(c, VO_ERR_CAPACITY, "vo_match_knn2_ratio: output capacity too small");
+    std::vector<int4> m(std::max(nm, 1));
+    if (nm) HIP_TRY(c, hipMemcpy(m.data(), c->d_mq.p, (size_t)nm * sizeof(int4), hipMemcpyDeviceToHost));
+    for (int i = 0; i < nm; i++) {
+        if (qidx) qidx[i] = m[i].x;
+        if (tidx) tidx[i] = m[i].y;
+        if (d1) d1[i] = m[i].z;
+        if (d2) d2[i] = m[i].w;
+    }
+    return VO_OK;
+}
+
+// -------------------------------------------------------------------- pose
+static int upload_points(vo_ctx* c, const float* q1, const float* q2, int n, hipStream_t st) {
+    if (n > c->kp_cap) return vo_fail(c, VO_ERR_CAPACITY, "more points than the context's keypoint capacity");
+    int hn = n, zero = 0;
+    HIP_TRY(c, hipMemcpyAsync(c->d_nmatch.p, &hn, 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(c, hipMemcpyAsync(c->d_pair_status.p, &zero, 4, hipMemcpyHostToDevice, st));
+    if (n) {
+        HIP_TRY(c, hipMemcpyAsync(c->d_q1.p, q1, (size_t)n * 8, hipMemcpyHostToDevice, st));
+        HIP_TRY(c, hipMemcpyAsync(c->d_q2.p, q2, (size_t)n * 8, hipMemcpyHostToDevice, st));
+    }
+    HIP_TRY(c, hipStreamSynchronize(st));  // the host scalars above are stack variables
+    return VO_OK;
+}
+
+int vo_find_essential_ransac(vo_ctx* c, const float* q1, const float* q2, int n, const double K[9], double prob, double thr, int max_iters,
+                             double E[9], uint8_t* mask, int* n_inliers) {
+    if (!c) return VO_ERR_INVALID;
+    if (!q1 || !q2 || !K || !E || n < 0) return vo_fail(c, VO_ERR_INVALID, "vo_find_essential_ransac: bad arguments");
+    if (!(prob > 0 && prob < 1)) return vo_fail(c, VO_ERR_INVALID, "vo_find_essential_ransac: confidence must be in (0,1)");
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    int rc = upload_points(c, q1, q2, n, st);
+    if (rc != VO_OK) return rc;
+    c->last_pairs = 1;
+    rc = vo_launch_ransac(c, 1, K, prob, thr, max_iters, st);
+    if (rc != VO_OK) return rc;
+    PoseWork w;
+    HIP_TRY(c, hipMemcpyAsync(&w, c->d_pose.p, sizeof(w), hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipStreamSynchronize(st));
+    if (n_inliers) *n_inliers = w.status == VO_OK ? w.max_good : 0;
+    if (w.status == VO_ERR_TOO_FEW) return vo_fail(c, VO_ERR_TOO_FEW, "findEssentialMat needs at least 5 points");
+    if (w.status != VO_OK) return vo_fail(c, w.status, "findEssentialMat: RANSAC found no model");
+    memcpy(E, w.E, sizeof(w.E));
+    if (mask && n) HIP_TRY(c, hipMemcpy(mask, c->d_mask.p, (size_t)n, hipMemcpyDeviceToHost));
+    return VO_OK;
+}
+
+int vo_recover_pose(vo_ctx* c, const double E[9], const float* q1, const float* q2, int n, const double K[9], double dist_thresh, double R[9],
+                    double t[3], int* n_good) {
+    if (!c) return VO_ERR_INVALID;
+    if (!E || !q1 || !q2 || !K || !R || !t || n < 0) return vo_fail(c, VO_ERR_INVALID, "vo_recover_pose: bad arguments");
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    int rc = upload_points(c, q1, q2, n, st);
+    if (rc != VO_OK) return rc;
+    PoseWork w;
+    memset(&w, 0, sizeof(w));
+    memcpy(w.E, E, sizeof(w.E));
+    w.status = VO_OK;
+    HIP_TRY(c, hipMemcpy(c->d_pose.p, &w, sizeof(w), hipMemcpyHostToDevice));
+    rc = vo_launch_recover(c, 1, K, dist_thresh, st);
+    if (rc != VO_OK) return rc;
+    HIP_TRY(c, hipMemcpyAsync(&w, c->d_pose.p, sizeof(w), hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipStreamSynchronize(st));
+    memcpy(R, w.R, sizeof(w.R));
+    memcpy(t, w.t, sizeof(w.t));
+    if (n_good) *n_good = w.n_good;
+    return VO_OK;
+}
+
+int vo_triangulate(vo_ctx* c, const double P1[12], const double P2[12], const float* x1, const float* x2, int n, float* X4) {
+    if (!c) return VO_ERR_INVALID;
+    if (!P1 || !P2 || !x1 || !x2 || !X4 || n < 0) return vo_fail(c, VO_ERR_INVALID, "vo_triangulate: bad arguments");
+    if (n == 0) return VO_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    const size_t need = 256 + (size_t)n * (8 + 8 + 16);
+    if (c->d_tri.bytes < need) {
+        dev_free(c->d_tri);
+        ALLOC(c, c->d_tri, need * 2);
+    }
+    uint8_t* base = (uint8_t*)c->d_tri.p;
+    double* dP = (double*)base;
+    float* dx1 = (float*)(base + 256);
+    float* dx2 = dx1 + (size_t)n * 2;
+    float* dX = dx2 + (size_t)n * 2;
+    HIP_TRY(c, hipMemcpyAsync(dP, P1, 96, hipMemcpyHostToDevice, st));
+    HIP_TRY(c, hipMemcpyAsync(dP + 12, P2, 96, hipMemcpyHostToDevice, st));
+    HIP_TRY(c, hipMemcpyAsync(dx1, x1, (size_t)n * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(c, hipMemcpyAsync(dx2, x2, (size_t)n * 8, hipMemcpyHostToDevice, st));
+    int rc = vo_launch_triangulate(c, dP, dx1, dx2, n, dX, st);
+    if (rc != VO_OK) return rc;
+    HIP_TRY(c, hipMemcpyAsync(X4, dX, (size_t)n * 16, hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipStreamSynchronize(st));
+    return VO_OK;
+}
+
+// -------------------------------------------------------------------- batched pairs
+int vo_pairs_run_device(vo_ctx* c, const uint8_t* imgsA, const uint8_t* imgsB, int B, int w, int h, int stride, const double K[9], double ratio,
+                        vo_pair_result* out, void* stream) {
+    if (!c) return VO_ERR_INVALID;
+    if (!imgsA || !imgsB || !K || !out || B < 0 || stride < w) return vo_fail(c, VO_ERR_INVALID, "vo_pairs_run_device: bad arguments");
+    if (B == 0) return VO_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    int rc = vo_build_geometry(c, w, h);
+    if (rc != VO_OK) return rc;
+    hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+    const long fs = (long)stride * h;
+    if (c->timing) for (int i = 0; i < VO_N_STAGES; i++) c->stage_ms[i] = 0;
+    for (int b0 = 0; b0 < B; b0 += c->max_pairs) {
+        const int Pb = std::min(c->max_pairs, B - b0);
+        for (int p0 = 0; p0 < Pb; p0 += c->chunk_pairs) {
+            const int Pc = std::min(c->chunk_pairs, Pb - p0);
+            FrameSrc src{imgsA + (long)(b0 + p0) * fs, imgsB + (long)(b0 + p0) * fs, Pc, stride, fs};
+            c->last_src = src; c->last_frames = 2 * Pc;
+            rc = vo_launch_detect(c, src, 2 * Pc, st);
+            if (rc != VO_OK) return rc;
+            rc = vo_launch_match_impl(c, Pc, Pc, ratio, p0, nullptr, st);
+            if (rc != VO_OK) return rc;
+            if (c->timing) {
+                HIP_TRY(c, hipEventRecord(c->ev[VO_STAGE_POSE], st));
+                HIP_TRY(c, hipStreamSynchronize(st));
+                for (int s = 0; s < VO_STAGE_POSE; s++) {
+                    float ms = 0;
+                    HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[s], c->ev[s + 1]));
+                    c->stage_ms[s] += ms;
+                }
+            }
+        }
+        c->last_pairs = Pb;
+        if (c->timing) HIP_TRY(c, hipEventRecord(c->ev[VO_STAGE_POSE], st));
+        rc = vo_launch_ransac(c, Pb, K, 0.999, 1.0, 1000, st);
+        if (rc != VO_OK) return rc;
+        rc = vo_launch_recover(c, Pb, K, 50.0, st);
+        if (rc != VO_OK) return rc;
+        hipLaunchKernelGGL(k_results, dim3((Pb + 63) / 64), dim3(64), 0, st, (const PoseWork*)c->d_pose.p, (const int*)c->d_nmatch.p,
+                           (const int2*)c->d_pair_nkp.p, Pb, (vo_pair_result*)c->d_result.p);
+        if (c->timing) HIP_TRY(c, hipEventRecord(c->ev[VO_N_STAGES], st));
+        HIP_TRY(c, hipMemcpyAsync(out + b0, c->d_result.p, (size_t)Pb * sizeof(vo_pair_result), hipMemcpyDeviceToHost, st));
+        HIP_TRY(c, hipStreamSynchronize(st));
+        if (c->timing) {
+            float ms = 0;
+            HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[VO_STAGE_POSE], c->ev[VO_N_STAGES]));
+            c->stage_ms[VO_STAGE_POSE] += ms;
+        }
+    }
+    return VO_OK;
+}
+
+int vo_pairs_run(vo_ctx* c, const uint8_t* imgsA, const uint8_t* imgsB, int B, int w, int h, int stride, const double K[9], double ratio,
+                 vo_pair_result* out) {
+    if (!c) return VO_ERR_INVALID;
+    if (!imgsA || !imgsB || B < 0 || stride < w) return vo_fail(c, VO_ERR_INVALID, "vo_pairs_run: bad arguments");
+    HIP_TRY(c, hipSetDevice(c->device));
+    // stage through device memory in super-batches of chunk_pairs pairs (d_img holds 2*chunk_pairs frames)
+    const long fs = (long)w * h;
+    for (int b0 = 0; b0 < B; b0 += c->chunk_pairs) {
+        const int Pc = std::min(c->chunk_pairs, B - b0);
+        if ((size_t)(2 * Pc * fs) > c->d_img.bytes) return vo_fail(c, VO_ERR_CAPACITY, "vo_pairs_run: staging buffer too small");
+        uint8_t* dA = (uint8_t*)c->d_img.p;
+        uint8_t* dB = dA + (long)Pc * fs;
+        HIP_TRY(c, hipMemcpy2D(dA, w, imgsA + (long)b0 * stride * h, stride, w, (size_t)h * Pc, hipMemcpyHostToDevice));
+        HIP_TRY(c, hipMemcpy2D(dB, w, imgsB + (long)b0 * stride * h, stride, w, (size_t)h * Pc, hipMemcpyHostToDevice));
+        int rc = vo_pairs_run_device(c, dA, dB, Pc, w, h, w, K, ratio, out + b0, nullptr);
+        if (rc != VO_OK) return rc;
+    }
+    return VO_OK;
+}
+
+// -------------------------------------------------------------------- stage read-back
+long vo_debug_read(vo_ctx* c, int what, int index, int level, void* out, long bytes) {
+    if (!c || (!c->geom_valid && what <= VO_DBG_DESCRIPTORS)) return VO_ERR_INVALID;
+    if (hipSetDevice(c->device) != hipSuccess) return VO_ERR_HIP;
+    (void)hipDeviceSynchronize();
+    const Geom& g = c->geom;
+    const long kc = c->kp_cap;
+    auto copy = [&](const void* src, long have) -> long {
+        if (out && have > 0 && bytes > 0 && hipMemcpy(out, src, (size_t)std::min(have, bytes), hipMemcpyDeviceToHost) != hipSuccess) return VO_ERR_HIP;
+        return have;
+    };
+    auto read_int = [&](const void* p, long idx) {
+        int v = 0;
+        (void)hipMemcpy(&v, (const int*)p + idx, 4, hipMemcpyDeviceToHost);
+        return v;
+    };
+    switch (what) {
+        case VO_DBG_PYR_LEVEL:
+        case VO_DBG_BLUR_LEVEL: {
+            if (index < 0 || index >= c->last_frames || level < 0 || level >= g.nlevels) return VO_ERR_INVALID;
+            const LevelGeom& L = g.lv[level];
+            const uint8_t* src;
+            long pitch;
+            if (what == VO_DBG_BLUR_LEVEL) { src = (const uint8_t*)c->d_blur.p + (long)index * g.blur_frame + L.blur_ofs; pitch = L.bpitch; }
+            else if (level == 0) {
+                const FrameSrc& s = c->last_src;
+                src = index < s.nA ? s.a + (long)index * s.frame_stride : s.b + (long)(index - s.nA) * s.frame_stride;
+                pitch = s.pitch;
+            } else { src = (const uint8_t*)c->d_pyr.p + (long)index * g.pyr_frame + L.pyr_ofs; pitch = L.pitch; }
+            const long have = (long)L.w * L.h;
+            if (out && bytes >= have && hipMemcpy2D(out, L.w, src, pitch, L.w, L.h, hipMemcpyDeviceToHost) != hipSuccess) return VO_ERR_HIP;
+            return have;
+        }
+        case VO_DBG_FAST_LIST:
+        case VO_DBG_SEL1_LIST:
+        case VO_DBG_SEL1_HARRIS: {
+            if (index < 0 || index >= c->last_frames || level < 0 || level >= g.nlevels) return VO_ERR_INVALID;
+            const int n = read_int(what == VO_DBG_FAST_LIST ? c->d_cnt_fast.p : c->d_cnt_sel1.p, (long)index * VO_MAX_LEVELS + level);
+            const long off = (long)index * g.cand_frame + g.lv[level].cand_ofs;
+            if (what == VO_DBG_SEL1_HARRIS) return copy((const float*)c->d_key.p + off, (long)n * 4);
+            const long have = (long)n * 12;
+            if (out && bytes >= have && n > 0) {
+                std::vector<uint32_t> pk(n);
+                if (hipMemcpy(pk.data(), (const uint32_t*)c->d_payload.p + off, (size_t)n * 4, hipMemcpyDeviceToHost) != hipSuccess) return VO_ERR_HIP;
+                int32_t* o = (int32_t*)out;
+                for (int i = 0; i < n; i++) { o[3 * i] = UNPACK_X(pk[i]); o[3 * i + 1] = UNPACK_Y(pk[i]); o[3 * i + 2] = UNPACK_S(pk[i]); }
+            }
+            return have;
+        }
+        case VO_DBG_KEYPOINTS:
+        case VO_DBG_DESCRIPTORS: {
+            if (index < 0 || index >= c->last_frames) return VO_ERR_INVALID;
+            const int n = read_int(c->d_nkp.p, index);
+            if (what == VO_DBG_KEYPOINTS) return copy((const vo_keypoint*)c->d_kp.p + (long)index * kc, (long)n * sizeof(vo_keypoint));
+            return copy((const uint8_t*)c->d_desc.p + (long)index * kc * 32, (long)n * 32);
+        }
+        case VO_DBG_MATCHES: {
+            if (index < 0 || index >= c->last_pairs) return VO_ERR_INVALID;
+            const int n = read_int(c->d_nmatch.p, index);
+            return copy((const int4*)c->d_mq.p + (long)index * kc, (long)n * 16);
+        }
+        case VO_DBG_E_MASK: {
+            if (index < 0 || index >= c->last_pairs) return VO_ERR_INVALID;
+            const int n = read_int(c->d_nmatch.p, index);
+            const long have = 72 + n;
+            if (out && bytes >= have) {
+                PoseWork w;
+                if (hipMemcpy(&w, (const PoseWork*)c->d_pose.p + index, sizeof(w), hipMemcpyDeviceToHost) != hipSuccess) return VO_ERR_HIP;
+                memcpy(out, w.E, 72);
+                if (n && hipMemcpy((uint8_t*)out + 72, (const uint8_t*)c->d_mask.p + (long)index * kc, n, hipMemcpyDeviceToHost) != hipSuccess) return VO_ERR_HIP;
+            }
+            return have;
+        }
+    }
+    return VO_ERR_INVALID;
+}
+
+}  // extern "C"

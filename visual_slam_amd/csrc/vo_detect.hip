@@ -1,0 +1,874 @@
+// vo_detect.hip -- ORB detect + describe for batches of frames on MI355X (gfx950).
+//
+// Stands behind orb.detectAndCompute(img, None) at /root/reference/libs/vo_utils.py:94-95
+// (OpenCV 4.8.0 ORB_Impl::detectAndCompute).  Stages, one launch each over
+// every frame of the chunk:
+//   k_pyramid (x7)  cascaded INTER_LINEAR_EXACT resize, 8.8 fixed point          [HBM bound]
+//   k_fast_tiles    FAST-9/16 + cornerScore + 3x3 NMS on 32x32 LDS tiles          [HBM bound]
+//   k_fast_scan     raster-order offsets of every (row, tile column) segment
+//   k_fast_emit     candidates to per-level lists in raster order
+//   k_select        KeyPointsFilter::retainBest: data-parallel replay of libstdc++
+//                   nth_element + partition (tests/introselect_model.py)
+//   k_harris        7x7 Harris response at the kept candidates
+//   k_select        second retainBest on the Harris response
+//   k_orient        intensity-centroid angle + final KeyPoint records
+//   k_blur          7x7 sigma=2 Gaussian of every level (sepFilter2D arithmetic)   [HBM bound]
+//   k_rbrief        rotated BRIEF-256, one wavefront per keypoint
+// All integer stages are bit exact by construction; float stages are compiled with
+// -ffp-contract=off and spell out fmaf where the CPU build of OpenCV contracts.
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstring>
+
+#include "vo_internal.h"
+
+// ------------------------------------------------------------------ host: geometry
+static inline int cvRoundF(float v) { return (int)nearbyintf(v); }
+static inline int cvRoundD(double v) { return (int)nearbyint(v); }
+static inline int cvFloorD(double v) { int i = (int)v; return i - (i > v); }
+static inline long align_up(long v, long a) { return (v + a - 1) / a * a; }
+
+static void linear_coeffs(int src, int dst, ResizeCoef* out) {
+    // interpolationLinear::getCoeffs of resize_bitExact
+    double inv_scale = (double)dst / src;
+    double scale = 1.0 / inv_scale;
+    for (int d = 0; d < dst; d++) {
+        double f = scale * ((double)d + 0.5) - 0.5;
+        int i = cvFloorD(f);
+        ResizeCoef c{0, 0, 0, 0};
+        if (i >= 0 && src > 1) {
+            if (i < src - 1) {
+                c.ofs0 = i; c.ofs1 = i + 1; c.c1 = cvRoundD((f - (double)i) * 256.0);
+            } else {
+                c.ofs0 = c.ofs1 = src - 1;
+            }
+        }
+        out[d] = c;
+    }
+}
+
+int vo_build_geometry(vo_ctx* c, int w, int h) {
+    if (c->geom_valid && c->geom.w == w && c->geom.h == h) return VO_OK;
+    const vo_orb_params& p = c->params;
+    if (w > c->max_w || h > c->max_h) return vo_fail(c, VO_ERR_INVALID, "image larger than the context was created for");
+    if (w < 64 || h < 64 || w > 4095 || h > 4095) return vo_fail(c, VO_ERR_INVALID, "image size out of range (64..4095)");
+    Geom g;
+    memset(&g, 0, sizeof(g));
+    g.nlevels = p.nlevels; g.w = w; g.h = h;
+    g.fast_threshold = p.fast_threshold; g.blur_mode = p.blur_mode; g.fma = p.fma;
+    const double scaleFactor = (double)p.scale_factor;
+    long pyr_ofs = 0, blur_ofs = 0, cand_ofs = 0;
+    int tile_base = 0, seg_base = 0, btile_base = 0, rt = 0;
+    for (int l = 0; l < p.nlevels; l++) {
+        LevelGeom& L = g.lv[l];
+        L.scale = (float)std::pow(scaleFactor, (double)l);
+        float inv = 1.f / L.scale;
+        L.w = cvRoundF(w * inv);
+        L.h = cvRoundF(h * inv);
+        if (L.w < 8 || L.h < 8) return vo_fail(c, VO_ERR_INVALID, "pyramid level too small");
+        L.pitch = (int)align_up(L.w, 64);
+        L.pyr_ofs = pyr_ofs;
+        if (l > 0) pyr_ofs += align_up((long)L.pitch * L.h, 256);
+        L.bpitch = (int)align_up(L.w, 64);
+        L.blur_ofs = blur_ofs;
+        blur_ofs += align_up((long)L.bpitch * L.h, 256);
+        bool has = (L.w > 2 * VO_EDGE) && (L.h > 2 * VO_EDGE);
+        L.iw = has ? L.w - 2 * VO_EDGE : 0;
+        L.ih = has ? L.h - 2 * VO_EDGE : 0;
+        L.ntx = (L.iw + VO_TILE - 1) / VO_TILE;
+        L.nty = (L.ih + VO_TILE - 1) / VO_TILE;
+        L.tile_base = tile_base;
+        tile_base += L.ntx * L.nty;
+        L.seg_base = seg_base;
+        seg_base += (int)align_up((long)L.ih * L.ntx, 16);
+        L.cand_cap = (int)align_up((long)((L.iw + 1) / 2) * ((L.ih + 1) / 2), 64);
+        L.cand_ofs = cand_ofs;
+        cand_ofs += L.cand_cap;
+        if (l > 0) {
+            L.xtab = rt; rt += L.w;
+            L.ytab = rt; rt += L.h;
+        }
+        L.bntx = (L.w + VO_BLUR_TW - 1) / VO_BLUR_TW;
+        L.bnty = (L.h + VO_BLUR_TH - 1) / VO_BLUR_TH;
+        L.btile_base = btile_base;
+        btile_base += L.bntx * L.bnty;
+    }
+    // per-level quota
+    {
+        float factor = (float)(1.0 / scaleFactor);
+        float nd = p.nfeatures * (1 - factor) / (1 - (float)std::pow((double)factor, (double)p.nlevels));
+        int sum = 0;
+        for (int l = 0; l < p.nlevels - 1; l++) {
+            g.lv[l].quota = cvRoundF(nd);
+            sum += g.lv[l].quota;
+            nd *= factor;
+        }
+        g.lv[p.nlevels - 1].quota = std::max(p.nfeatures - sum, 0);
+    }
+    g.ntiles = tile_base; g.nsegs = seg_base; g.nbtiles = btile_base;
+    g.pyr_frame = align_up(pyr_ofs, 256); g.blur_frame = align_up(blur_ofs, 256);
+    g.cand_frame = cand_ofs;
+    g.kp_cap = c->kp_cap;
+
+    c->h_tiles.assign(std::max(g.ntiles, 1), TileDesc{0, 0, 0, 0});
+    c->h_btiles.assign(std::max(g.nbtiles, 1), TileDesc{0, 0, 0, 0});
+    c->h_rtab.assign(std::max(rt, 1), ResizeCoef{0, 0, 0, 0});
+    for (int l = 0; l < p.nlevels; l++) {
+        const LevelGeom& L = g.lv[l];
+        for (int ty = 0; ty < L.nty; ty++)
+            for (int tx = 0; tx < L.ntx; tx++) c->h_tiles[L.tile_base + ty * L.ntx + tx] = TileDesc{(short)l, (short)tx, (short)ty, 0};
+        for (int ty = 0; ty < L.bnty; ty++)
+            for (int tx = 0; tx < L.bntx; tx++) c->h_btiles[L.btile_base + ty * L.bntx + tx] = TileDesc{(short)l, (short)tx, (short)ty, 0};
+        if (l > 0) {
+            linear_coeffs(g.lv[l - 1].w, L.w, &c->h_rtab[L.xtab]);
+            linear_coeffs(g.lv[l - 1].h, L.h, &c->h_rtab[L.ytab]);
+        }
+    }
+    // workspace capacity check against what vo_ctx_create allocated (sized for max_w x max_h)
+    const long F = c->max_frames;
+    if ((size_t)(g.pyr_frame * F) > c->d_pyr.bytes || (size_t)(g.blur_frame * F) > c->d_blur.bytes ||
+        (size_t)(g.cand_frame * F * 4) > c->d_key.bytes || (size_t)((long)g.ntiles * F * VO_TILE_CAP * 4) > c->d_tile_list.bytes ||
+        (size_t)((long)g.nsegs * F) > c->d_seg_cnt.bytes || c->h_tiles.size() * sizeof(TileDesc) > c->d_tiles.bytes ||
+        c->h_btiles.size() * sizeof(TileDesc) > c->d_btiles.bytes || c->h_rtab.size() * sizeof(ResizeCoef) > c->d_rtab.bytes)
+        return vo_fail(c, VO_ERR_CAPACITY, "workspace too small for this image size");
+    HIP_TRY(c, hipMemcpy(c->d_geom.p, &g, sizeof(g), hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->d_tiles.p, c->h_tiles.data(), c->h_tiles.size() * sizeof(TileDesc), hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->d_btiles.p, c->h_btiles.data(), c->h_btiles.size() * sizeof(TileDesc), hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->d_rtab.p, c->h_rtab.data(), c->h_rtab.size() * sizeof(ResizeCoef), hipMemcpyHostToDevice));
+    c->geom = g;
+    c->geom_valid = true;
+    return VO_OK;
+}
+
+// ------------------------------------------------------------------ pyramid
+// level l from level l-1: H = c0x*p[i] + c1x*p[i+1] (u16), out = (c0y*H0 + c1y*H1 + 32768) >> 16.
+// One thread makes 4 adjacent pixels and stores them as one dword.
+__global__ __launch_bounds__(256) void k_pyramid(const Geom* __restrict__ g, FrameSrc src, uint8_t* __restrict__ pyr,
+                                                 const ResizeCoef* __restrict__ rt, int l) {
+    const LevelGeom& L = g->lv[l];
+    const int f = blockIdx.z;
+    const int x4 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (y >= L.h || x4 >= L.w) return;
+    int spitch;
+    const uint8_t* sp = level_ptr(g, src, pyr, f, l - 1, spitch);
+    const ResizeCoef cy = rt[L.ytab + y];
+    const uint8_t* r0 = sp + (long)cy.ofs0 * spitch;
+    const uint8_t* r1 = sp + (long)cy.ofs1 * spitch;
+    const uint32_t c1y = cy.c1, c0y = 256 - cy.c1;
+    uint32_t packed = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        int x = x4 + i;
+        if (x < L.w) {
+            const ResizeCoef cx = rt[L.xtab + x];
+            uint32_t c1 = cx.c1, c0 = 256 - cx.c1;
+            uint32_t h0 = c0 * r0[cx.ofs0] + c1 * r0[cx.ofs1];
+            uint32_t h1 = c0 * r1[cx.ofs0] + c1 * r1[cx.ofs1];
+            uint32_t o = (c0y * h0 + c1y * h1 + 32768u) >> 16;
+            packed |= o << (8 * i);
+        }
+    }
+    uint8_t* dp = pyr + (long)f * g->pyr_frame + L.pyr_ofs + (long)y * L.pitch + x4;
+    *reinterpret_cast<uint32_t*>(dp) = packed;
+}
+
+// ------------------------------------------------------------------ FAST-9/16
+__device__ __forceinline__ bool has9(uint32_t m) {
+    m |= m << 16;
+    uint32_t a = m & (m >> 1);
+    a &= a >> 2;
+    a &= a >> 4;
+    a &= m >> 8;
+    return (a & 0xFFFFu) != 0;
+}
+
+#define PXP 48  // LDS pixel tile pitch
+// circle offsets k = 0..15 as (dx,dy): (0,3)(1,3)(2,2)(3,1)(3,0)(3,-1)(2,-2)(1,-3)(0,-3)(-1,-3)(-2,-2)(-3,-1)(-3,0)(-3,1)(-2,2)(-1,3)
+#define CIRC(k) (((k) == 0 ? 3 : (k) == 1 ? 3 : (k) == 2 ? 2 : (k) == 3 ? 1 : (k) == 4 ? 0 : (k) == 5 ? -1 : (k) == 6 ? -2 : (k) == 7 ? -3 : \
+                  (k) == 8 ? -3 : (k) == 9 ? -3 : (k) == 10 ? -2 : (k) == 11 ? -1 : (k) == 12 ? 0 : (k) == 13 ? 1 : (k) == 14 ? 2 : 3) * PXP + \
+                 ((k) == 0 ? 0 : (k) == 1 ? 1 : (k) == 2 ? 2 : (k) == 3 ? 3 : (k) == 4 ? 3 : (k) == 5 ? 3 : (k) == 6 ? 2 : (k) == 7 ? 1 : \
+                  (k) == 8 ? 0 : (k) == 9 ? -1 : (k) == 10 ? -2 : (k) == 11 ? -3 : (k) == 12 ? -3 : (k) == 13 ? -3 : (k) == 14 ? -2 : -1))
+
+// 0 for a non-corner, else cornerScore<16> (largest threshold that keeps it a corner, minus 1)
+__device__ __forceinline__ int fast_score_lds(const uint8_t* p, int thr) {
+    const int v = p[0];
+    int d[16];
+    uint32_t md = 0, mb = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        d[k] = v - (int)p[CIRC(k)];
+        md |= (uint32_t)(d[k] > thr) << k;
+        mb |= (uint32_t)(d[k] < -thr) << k;
+    }
+    if (!(has9(md) || has9(mb))) return 0;
+    // max over the 16 arcs of 9 of min(d) and of min(-d), by doubling
+    int lo2[16], hi2[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) { lo2[k] = min(d[k], d[(k + 1) & 15]); hi2[k] = max(d[k], d[(k + 1) & 15]); }
+    int lo4[16], hi4[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) { lo4[k] = min(lo2[k], lo2[(k + 2) & 15]); hi4[k] = max(hi2[k], hi2[(k + 2) & 15]); }
+    int A = -1000, B = 1000;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        int lo9 = min(min(lo4[k], lo4[(k + 4) & 15]), d[(k + 8) & 15]);
+        int hi9 = max(max(hi4[k], hi4[(k + 4) & 15]), d[(k + 8) & 15]);
+        A = max(A, lo9);
+        B = min(B, hi9);
+    }
+    return max(A, -B) - 1;
+}
+
+__global__ __launch_bounds__(256) void k_fast_tiles(const Geom* __restrict__ g, FrameSrc src, const uint8_t* __restrict__ pyr,
+                                                    const TileDesc* __restrict__ tiles, uint32_t* __restrict__ tile_list,
+                                                    uint8_t* __restrict__ seg_cnt) {
+    __shared__ uint8_t px[40 * PXP];
+    __shared__ uint8_t sc[34 * 36];
+    __shared__ int wtot[4];
+    const int t = blockIdx.x, f = blockIdx.y, tid = threadIdx.x;
+    const TileDesc td = tiles[t];
+    const LevelGeom& L = g->lv[td.level];
+    int pitch;
+    const uint8_t* img = level_ptr(g, src, pyr, f, td.level, pitch);
+    const int x0 = VO_EDGE + td.tx * VO_TILE, y0 = VO_EDGE + td.ty * VO_TILE;
+    for (int i = tid; i < 40 * 40; i += 256) {
+        int r = i / 40, c = i - r * 40;
+        int y = min(y0 - 4 + r, L.h - 1), x = min(x0 - 4 + c, L.w - 1);
+        px[r * PXP + c] = img[(long)y * pitch + x];
+    }
+    __syncthreads();
+    const int thr = g->fast_threshold;
+    for (int i = tid; i < 34 * 34; i += 256) {
+        int r = i / 34, c = i - r * 34;
+        int xi = x0 - 1 + c, yi = y0 - 1 + r;
+        int s = 0;
+        if (xi < L.w - 3 && yi < L.h - 3) s = fast_score_lds(&px[(r + 3) * PXP + c + 3], thr);
+        sc[r * 36 + c] = (uint8_t)s;
+    }
+    __syncthreads();
+    // 3x3 non-max suppression (strict) + border filter; thread = 4 adjacent pixels of one row
+    const int r = tid >> 3, c4 = (tid & 7) * 4;
+    const int yi = y0 + r;
+    uint32_t ent[2] = {0, 0};
+    int cnt = 0;
+    if (yi < L.h - VO_EDGE) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            int c = c4 + j, xi = x0 + c;
+            const uint8_t* q = &sc[(r + 1) * 36 + c + 1];
+            int s = q[0];
+            bool keep = s != 0 && xi < L.w - VO_EDGE && s > q[-1] && s > q[1] && s > q[-37] && s > q[-36] && s > q[-35] && s > q[35] &&
+                        s > q[36] && s > q[37];
+            if (keep && cnt < 2) ent[cnt++] = PACK_XYS(xi, yi, s);
+        }
+    }
+    const int lane = tid & 63, wave = tid >> 6;
+    int incl = cnt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        int v = __shfl_up(incl, o);
+        if (lane >= o) incl += v;
+    }
+    if (lane == 63) wtot[wave] = incl;
+    __syncthreads();
+    int base = 0;
+    for (int w2 = 0; w2 < wave; w2++) base += wtot[w2];
+    const int excl = base + incl - cnt;
+    uint32_t* tl = tile_list + ((long)f * g->ntiles + t) * VO_TILE_CAP;
+    if (cnt > 0) tl[excl] = ent[0];
+    if (cnt > 1) tl[excl + 1] = ent[1];
+    int row_end = __shfl_down(incl, 7);
+    if ((tid & 7) == 0 && td.ty * VO_TILE + r < L.ih) {
+        int rc = row_end - (incl - cnt);
+        seg_cnt[(long)f * g->nsegs + L.seg_base + (long)(td.ty * VO_TILE + r) * L.ntx + td.tx] = (uint8_t)rc;
+    }
+}
+
+// exclusive scan over the (row, tile column) segments of one level in raster order
+__global__ __launch_bounds__(256) void k_fast_scan(const Geom* __restrict__ g, const uint8_t* __restrict__ seg_cnt,
+                                                   uint32_t* __restrict__ seg_ofs, int* __restrict__ cnt_fast) {
+    __shared__ int wtot[4];
+    const int l = blockIdx.x, f = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const LevelGeom& L = g->lv[l];
+    const int S = L.ih * L.ntx;
+    const uint8_t* cp = seg_cnt + (long)f * g->nsegs + L.seg_base;
+    uint32_t* op = seg_ofs + (long)f * g->nsegs + L.seg_base;
+    int running = 0;
+    for (int base = 0; base < S; base += 256 * 16) {
+        const int i0 = base + tid * 16;
+        uint8_t v[16];
+        if (i0 + 16 <= S) {
+            uint4 q = *reinterpret_cast<const uint4*>(cp + i0);
+            memcpy(v, &q, 16);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 16; j++) v[j] = (i0 + j < S) ? cp[i0 + j] : 0;
+        }
+        int sum = 0;
+#pragma unroll
+        for (int j = 0; j < 16; j++) sum += v[j];
+        int incl = sum;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            int u = __shfl_up(incl, o);
+            if (lane >= o) incl += u;
+        }
+        if (lane == 63) wtot[wave] = incl;
+        __syncthreads();
+        int wbase = 0, tot = 0;
+        for (int w2 = 0; w2 < 4; w2++) {
+            if (w2 < wave) wbase += wtot[w2];
+            tot += wtot[w2];
+        }
+        int pre = running + wbase + incl - sum;
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            if (i0 + j < S) op[i0 + j] = pre;
+            pre += v[j];
+        }
+        running += tot;
+        __syncthreads();
+    }
+    if (tid == 0) cnt_fast[f * VO_MAX_LEVELS + l] = running;
+}
+
+// tile lists -> per-level candidate lists in raster order: key = FAST score, payload = packed x,y,score
+__global__ __launch_bounds__(64) void k_fast_emit(const Geom* __restrict__ g, const TileDesc* __restrict__ tiles,
+                                                  const uint32_t* __restrict__ tile_list, const uint8_t* __restrict__ seg_cnt,
+                                                  const uint32_t* __restrict__ seg_ofs, float* __restrict__ key, uint32_t* __restrict__ payload) {
+    __shared__ int rowstart[33];
+    __shared__ uint32_t rowofs[32];
+    const int t = blockIdx.x, f = blockIdx.y, lane = threadIdx.x;
+    const TileDesc td = tiles[t];
+    const LevelGeom& L = g->lv[td.level];
+    const int rows = min(VO_TILE, L.ih - td.ty * VO_TILE);
+    int c = 0;
+    if (lane < rows) {
+        long s = (long)f * g->nsegs + L.seg_base + (long)(td.ty * VO_TILE + lane) * L.ntx + td.tx;
+        c = seg_cnt[s];
+        rowofs[lane] = seg_ofs[s];
+    }
+    int incl = c;
+#pragma unroll
+    for (int o = 1; o < 32; o <<= 1) {
+        int u = __shfl_up(incl, o);
+        if (lane >= o) incl += u;
+    }
+    if (lane < 32) rowstart[lane + 1] = incl;
+    if (lane == 0) rowstart[0] = 0;
+    __syncthreads();
+    const int total = rowstart[32];
+    const uint32_t* tl = tile_list + ((long)f * g->ntiles + t) * VO_TILE_CAP;
+    const long cb = (long)f * g->cand_frame + L.cand_ofs;
+    for (int e = lane; e < total; e += 64) {
+        int r = 0;
+        while (rowstart[r + 1] <= e) r++;
+        uint32_t p = tl[e];
+        long o = cb + rowofs[r] + (e - rowstart[r]);
+        key[o] = (float)UNPACK_S(p);
+        payload[o] = p;
+    }
+}
+
+// ------------------------------------------------------------------ retainBest
+// Sequential pieces of libstdc++ (bits/stl_algo.h, bits/stl_heap.h) on (key, payload) pairs;
+// comp(a, b) = key[a] > key[b].  Executed by one lane.
+__device__ inline void sel_swap(float* key, uint32_t* pay, int i, int j) {
+    float k = key[i]; key[i] = key[j]; key[j] = k;
+    uint32_t p = pay[i]; pay[i] = pay[j]; pay[j] = p;
+}
+__device__ inline void sel_median_to_first(float* key, uint32_t* pay, int result, int a, int b, int c) {
+    float ka = key[a], kb = key[b], kc = key[c];
+    if (ka > kb) {
+        if (kb > kc) sel_swap(key, pay, result, b);
+        else if (ka > kc) sel_swap(key, pay, result, c);
+        else sel_swap(key, pay, result, a);
+    } else if (ka > kc) sel_swap(key, pay, result, a);
+    else if (kb > kc) sel_swap(key, pay, result, c);
+    else sel_swap(key, pay, result, b);
+}
+__device__ inline void sel_insertion_sort(float* key, uint32_t* pay, int first, int last) {
+    for (int i = first + 1; i < last; i++)
+        for (int j = i; j > first && key[j] > key[j - 1]; j--) sel_swap(key, pay, j, j - 1);
+}
+__device__ inline void sel_adjust_heap(float* key, uint32_t* pay, int first, int hole, int len, float vk, uint32_t vp) {
+    const int top = hole;
+    int child = hole;
+    while (child < (len - 1) / 2) {
+        child = 2 * (child + 1);
+        if (key[first + child] > key[first + child - 1]) child--;
+        key[first + hole] = key[first + child]; pay[first + hole] = pay[first + child];
+        hole = child;
+    }
+    if ((len & 1) == 0 && child == (len - 2) / 2) {
+        child = 2 * (child + 1);
+        key[first + hole] = key[first + child - 1]; pay[first + hole] = pay[first + child - 1];
+        hole = child - 1;
+    }
+    int parent = (hole - 1) / 2;
+    while (hole > top && key[first + parent] > vk) {
+        key[first + hole] = key[first + parent]; pay[first + hole] = pay[first + parent];
+        hole = parent;
+        parent = (hole - 1) / 2;
+    }
+    key[first + hole] = vk; pay[first + hole] = vp;
+}
+__device__ inline void sel_heap_select(float* key, uint32_t* pay, int first, int nth, int last) {
+    const int middle = nth + 1, len = middle - first;
+    if (len >= 2) {
+        for (int parent = (len - 2) / 2;; parent--) {
+            sel_adjust_heap(key, pay, first, parent, len, key[first + parent], pay[first + parent]);
+            if (parent == 0) break;
+        }
+    }
+    for (int i = middle; i < last; i++)
+        if (key[i] > key[first]) {
+            float vk = key[i]; uint32_t vp = pay[i];
+            key[i] = key[first]; pay[i] = pay[first];
+            sel_adjust_heap(key, pay, first, 0, len, vk, vp);
+        }
+    sel_swap(key, pay, first, nth);
+}
+
+// Hoare partition of [lo,hi) resolved in closed form (tests/introselect_model.py).
+// MODE 0: __unguarded_partition around pivot p: left stoppers !(k > p), right stoppers !(p > k);
+//         returns the cut.
+// MODE 1: std::partition with pred k >= p: left stoppers !(k >= p), right stoppers (k >= p);
+//         returns the number of elements satisfying pred.
+template <int NT, int MODE>
+__device__ int sel_partition(float* key, uint32_t* pay, uint32_t* lpos, uint32_t* rpos, int lo, int hi, float p, int* s_wl, int* s_wr, int* s_K) {
+    constexpr int NW = NT / 64;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int len = hi - lo;
+    const int chunk = (((len + NW - 1) / NW) + 63) & ~63;
+    const int wlo = lo + w * chunk, whi = min(wlo + chunk, hi);
+    int cl = 0, cr = 0;
+    for (int b = wlo; b < whi; b += 64) {
+        int i = b + lane;
+        bool in = i < whi;
+        float k = in ? key[i] : 0.f;
+        bool isL = in && (MODE == 0 ? !(k > p) : !(k >= p));
+        bool isR = in && (MODE == 0 ? !(p > k) : (k >= p));
+        cl += __popcll(__ballot(isL));
+        cr += __popcll(__ballot(isR));
+    }
+    if (lane == 0) { s_wl[w] = cl; s_wr[w] = cr; }
+    __syncthreads();
+    if (tid == 0) *s_K = 0;
+    int baseL = 0, baseR = 0, totL = 0, totR = 0;
+    for (int w2 = 0; w2 < NW; w2++) {
+        int a = s_wl[w2], b = s_wr[w2];
+        if (w2 < w) { baseL += a; baseR += b; }
+        totL += a; totR += b;
+    }
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    int rl = baseL, rr = baseR;
+    for (int b = wlo; b < whi; b += 64) {
+        int i = b + lane;
+        bool in = i < whi;
+        float k = in ? key[i] : 0.f;
+        bool isL = in && (MODE == 0 ? !(k > p) : !(k >= p));
+        bool isR = in && (MODE == 0 ? !(p > k) : (k >= p));
+        unsigned long long mL = __ballot(isL), mR = __ballot(isR);
+        if (isL) lpos[rl + __popcll(mL & lt)] = (uint32_t)i;
+        if (isR) rpos[totR - 1 - (rr + __popcll(mR & lt))] = (uint32_t)i;
+        rl += __popcll(mL);
+        rr += __popcll(mR);
+    }
+    __syncthreads();
+    const int m = min(totL, totR);
+    int ck = 0;
+    for (int k = tid; k < m; k += NT) ck += (lpos[k] < rpos[k]) ? 1 : 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ck += __shfl_xor(ck, o);
+    if (lane == 0 && ck) atomicAdd(s_K, ck);
+    __syncthreads();
+    const int K = *s_K;
+    for (int k = tid; k < K; k += NT) sel_swap(key, pay, (int)lpos[k], (int)rpos[k]);
+    int ret;
+    if (MODE == 0) {
+        if (K == 0) ret = (int)lpos[0];
+        else {
+            ret = (int)rpos[K - 1];
+            if (K < totL) ret = min(ret, (int)lpos[K]);
+        }
+    } else {
+        ret = totR;
+    }
+    __syncthreads();
+    return ret;
+}
+
+// KeyPointsFilter::retainBest(list, mult*quota) for every (frame, level) list of the chunk.
+template <int NT>
+__global__ __launch_bounds__(NT) void k_select(const Geom* __restrict__ g, float* key, uint32_t* pay, uint32_t* lpos, uint32_t* rpos,
+                                               const int* __restrict__ cnt_in, int* __restrict__ cnt_out, int mult) {
+    __shared__ int s_wl[NT / 64], s_wr[NT / 64], s_K;
+    const int l = blockIdx.x, f = blockIdx.y, tid = threadIdx.x;
+    const LevelGeom& L = g->lv[l];
+    const long base = (long)f * g->cand_frame + L.cand_ofs;
+    key += base; pay += base; lpos += base; rpos += base;
+    const int n = cnt_in[f * VO_MAX_LEVELS + l];
+    const int np = mult * L.quota;
+    if (!(n > np)) {
+        if (tid == 0) cnt_out[f * VO_MAX_LEVELS + l] = n;
+        return;
+    }
+    if (np == 0) {
+        if (tid == 0) cnt_out[f * VO_MAX_LEVELS + l] = 0;
+        return;
+    }
+    int first = 0, last = n;
+    const int nth = np - 1;
+    int depth = 2 * (31 - __clz(n));
+    bool heap_done = false;
+    while (last - first > 3) {
+        if (depth == 0) {
+            if (tid == 0) sel_heap_select(key, pay, first, nth, last);
+            __syncthreads();
+            heap_done = true;
+            break;
+        }
+        --depth;
+        if (tid == 0) sel_median_to_first(key, pay, first, first + 1, first + (last - first) / 2, last - 1);
+        __syncthreads();
+        const float p = key[first];
+        const int cut = sel_partition<NT, 0>(key, pay, lpos, rpos, first + 1, last, p, s_wl, s_wr, &s_K);
+        if (cut <= nth) first = cut;
+        else last = cut;
+    }
+    if (!heap_done && tid == 0) sel_insertion_sort(key, pay, first, last);
+    __syncthreads();
+    const float amb = key[np - 1];
+    const int totT = sel_partition<NT, 1>(key, pay, lpos, rpos, np, n, amb, s_wl, s_wr, &s_K);
+    if (tid == 0) cnt_out[f * VO_MAX_LEVELS + l] = np + totT;
+}
+
+// ------------------------------------------------------------------ Harris (HarrisResponses, blockSize 7)
+__global__ __launch_bounds__(256) void k_harris(const Geom* __restrict__ g, FrameSrc src, const uint8_t* __restrict__ pyr,
+                                                const int* __restrict__ cnt, float* __restrict__ key, const uint32_t* __restrict__ payload) {
+    const int l = blockIdx.y, f = blockIdx.z;
+    const LevelGeom& L = g->lv[l];
+    const int n = cnt[f * VO_MAX_LEVELS + l];
+    int pitch;
+    const uint8_t* img = level_ptr(g, src, pyr, f, l, pitch);
+    const long cb = (long)f * g->cand_frame + L.cand_ofs;
+    const float scale = 1.f / ((1 << 2) * 7 * 255.f);
+    const float scale_sq_sq = scale * scale * scale * scale;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const uint32_t p = payload[cb + i];
+        const uint8_t* c0 = img + (long)(UNPACK_Y(p) - 4) * pitch + (UNPACK_X(p) - 4);
+        // 9x9 window; Ix, Iy at the inner 7x7
+        int a = 0, b = 0, c = 0;
+        uint8_t r0[9], r1[9], r2[9];
+#pragma unroll
+        for (int j = 0; j < 9; j++) { r0[j] = c0[j]; r1[j] = c0[pitch + j]; }
+#pragma unroll
+        for (int y = 1; y <= 7; y++) {
+            const uint8_t* rp = c0 + (long)(y + 1) * pitch;
+#pragma unroll
+            for (int j = 0; j < 9; j++) r2[j] = rp[j];
+#pragma unroll
+            for (int x = 1; x <= 7; x++) {
+                int Ix = ((int)r1[x + 1] - (int)r1[x - 1]) * 2 + ((int)r0[x + 1] - (int)r0[x - 1]) + ((int)r2[x + 1] - (int)r2[x - 1]);
+                int Iy = ((int)r2[x] - (int)r0[x]) * 2 + ((int)r2[x - 1] - (int)r0[x - 1]) + ((int)r2[x + 1] - (int)r0[x + 1]);
+                a += Ix * Ix;
+                b += Iy * Iy;
+                c += Ix * Iy;
+            }
+#pragma unroll
+            for (int j = 0; j < 9; j++) { r0[j] = r1[j]; r1[j] = r2[j]; }
+        }
+        const float fa = (float)a, fb = (float)b, fc = (float)c;
+        const float t1 = fa * fb;
+        const float t2 = fc * fc;
+        const float s = fa + fb;
+        const float t4 = 0.04f * s;
+        const float t5 = t4 * s;
+        key[cb + i] = ((t1 - t2) - t5) * scale_sq_sq;
+    }
+}
+
+// ------------------------------------------------------------------ orientation + KeyPoint records
+__device__ __forceinline__ float fast_atan2_deg(float y, float x, bool use_fma) {
+    const float p1 = 0.9997878412794807f * (float)(180 / M_PI);
+    const float p3 = -0.3258083974640975f * (float)(180 / M_PI);
+    const float p5 = 0.1555786518463281f * (float)(180 / M_PI);
+    const float p7 = -0.04432655554792128f * (float)(180 / M_PI);
+    const float ax = fabsf(x), ay = fabsf(y);
+    float a, c, c2;
+    if (ax >= ay) {
+        c = ay / (ax + (float)DBL_EPSILON);
+        c2 = c * c;
+        if (use_fma) a = __fmaf_rn(__fmaf_rn(__fmaf_rn(p7, c2, p5), c2, p3), c2, p1) * c;
+        else a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    } else {
+        c = ax / (ay + (float)DBL_EPSILON);
+        c2 = c * c;
+        if (use_fma) a = __fmaf_rn(-__fmaf_rn(__fmaf_rn(__fmaf_rn(p7, c2, p5), c2, p3), c2, p1), c, 90.f);
+        else a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    }
+    if (x < 0) a = 180.f - a;
+    if (y < 0) a = 360.f - a;
+    return a;
+}
+
+__constant__ int c_umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
+
+// 32 lanes per keypoint: lane = column u+15, loop over the 31 rows of the disc.
+__global__ __launch_bounds__(256) void k_orient(const Geom* __restrict__ g, FrameSrc src, const uint8_t* __restrict__ pyr,
+                                                const int* __restrict__ cnt_sel2, const float* __restrict__ key,
+                                                const uint32_t* __restrict__ payload, vo_keypoint* __restrict__ kps,
+                                                uint32_t* __restrict__ kplvl, int* __restrict__ nkp, int* __restrict__ frame_status) {
+    const int l = blockIdx.y, f = blockIdx.z;
+    const LevelGeom& L = g->lv[l];
+    int off = 0, total = 0;
+    for (int l2 = 0; l2 < g->nlevels; l2++) {
+        int c = cnt_sel2[f * VO_MAX_LEVELS + l2];
+        if (l2 < l) off += c;
+        total += c;
+    }
+    const int n = cnt_sel2[f * VO_MAX_LEVELS + l];
+    if (l == 0 && blockIdx.x == 0 && threadIdx.x == 0) {
+        nkp[f] = min(total, g->kp_cap);
+        frame_status[f] = total > g->kp_cap ? VO_ERR_CAPACITY : VO_OK;
+    }
+    int pitch;
+    const uint8_t* img = level_ptr(g, src, pyr, f, l, pitch);
+    const long cb = (long)f * g->cand_frame + L.cand_ofs;
+    const int sub = threadIdx.x >> 5, u = (threadIdx.x & 31) - 15;
+    for (int i = blockIdx.x * 8 + sub; i < n; i += gridDim.x * 8) {
+        const uint32_t p = payload[cb + i];
+        const int x0 = UNPACK_X(p), y0 = UNPACK_Y(p);
+        const uint8_t* center = img + (long)y0 * pitch + x0;
+        int m10 = 0, m01 = 0;
+        if (u <= 15) {
+            const int au = u < 0 ? -u : u;
+#pragma unroll
+            for (int v = -15; v <= 15; v++) {
+                const int av = v < 0 ? -v : v;
+                if (au <= c_umax[av]) {
+                    int val = center[(long)v * pitch + u];
+                    m10 += u * val;
+                    m01 += v * val;
+                }
+            }
+        }
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) {
+            m10 += __shfl_xor(m10, o);
+            m01 += __shfl_xor(m01, o);
+        }
+        if ((threadIdx.x & 31) == 0 && off + i < g->kp_cap) {
+            vo_keypoint k;
+            k.x = (float)x0 * L.scale;
+            k.y = (float)y0 * L.scale;
+            k.size = 31 * L.scale;
+            k.angle = fast_atan2_deg((float)m01, (float)m10, g->fma != 0);
+            k.response = key[cb + i];
+            k.octave = l;
+            const long o = (long)f * g->kp_cap + off + i;
+            kps[o] = k;
+            kplvl[o] = PACK_XYS(x0, y0, l);
+        }
+    }
+}
+
+// ------------------------------------------------------------------ 7x7 sigma=2 blur
+__device__ __forceinline__ int reflect101c(int i, int n) {
+    if (i < 0) i = -i;
+    if (i >= n) i = 2 * n - 2 - i;
+    return min(max(i, 0), n - 1);
+}
+
+struct BlurK { float k[4]; };  // k[0] = centre weight, k[i] = weight at distance i
+
+__global__ __launch_bounds__(256) void k_blur(const Geom* __restrict__ g, FrameSrc src, const uint8_t* __restrict__ pyr,
+                                              uint8_t* __restrict__ blur, const TileDesc* __restrict__ btiles, BlurK bk) {
+    __shared__ uint8_t sp[(VO_BLUR_TH + 6) * 72];
+    __shared__ float rowf[(VO_BLUR_TH + 6) * VO_BLUR_TW];
+    const int f = blockIdx.y, tid = threadIdx.x;
+    const TileDesc td = btiles[blockIdx.x];
+    const LevelGeom& L = g->lv[td.level];
+    int pitch;
+    const uint8_t* img = level_ptr(g, src, pyr, f, td.level, pitch);
+    const int x0 = td.tx * VO_BLUR_TW, y0 = td.ty * VO_BLUR_TH;
+    for (int i = tid; i < (VO_BLUR_TH + 6) * 70; i += 256) {
+        int r = i / 70, c = i - r * 70;
+        int y = reflect101c(y0 - 3 + r, L.h), x = reflect101c(x0 - 3 + c, L.w);
+        sp[r * 72 + c] = img[(long)y * pitch + x];
+    }
+    __syncthreads();
+    const bool use_fma = g->fma != 0;
+    const int mode = g->blur_mode;
+    int* rowi = reinterpret_cast<int*>(rowf);
+    for (int i = tid; i < (VO_BLUR_TH + 6) * VO_BLUR_TW; i += 256) {
+        int r = i / VO_BLUR_TW, c = i - r * VO_BLUR_TW;
+        const uint8_t* q = &sp[r * 72 + c];
+        if (mode == 1) {
+            rowi[i] = 18 * (q[0] + q[6]) + 34 * (q[1] + q[5]) + 49 * (q[2] + q[4]) + 55 * q[3];
+        } else {
+            // RowFilter<uchar,float>: s = k[0]*p[-3]; s += k[j]*p[j-3] left to right
+            float acc = bk.k[3] * (float)q[0];
+            if (use_fma) {
+                acc = __fmaf_rn(bk.k[2], (float)q[1], acc);
+                acc = __fmaf_rn(bk.k[1], (float)q[2], acc);
+                acc = __fmaf_rn(bk.k[0], (float)q[3], acc);
+                acc = __fmaf_rn(bk.k[1], (float)q[4], acc);
+                acc = __fmaf_rn(bk.k[2], (float)q[5], acc);
+                acc = __fmaf_rn(bk.k[3], (float)q[6], acc);
+            } else {
+                acc = acc + bk.k[2] * (float)q[1];
+                acc = acc + bk.k[1] * (float)q[2];
+                acc = acc + bk.k[0] * (float)q[3];
+                acc = acc + bk.k[1] * (float)q[4];
+                acc = acc + bk.k[2] * (float)q[5];
+                acc = acc + bk.k[3] * (float)q[6];
+            }
+            rowf[i] = acc;
+        }
+    }
+    __syncthreads();
+    const int r = tid >> 4, c4 = (tid & 15) * 4;
+    const int y = y0 + r;
+    if (y >= L.h || x0 + c4 >= L.w) return;
+    uint32_t packed = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int c = c4 + j;
+        int o;
+        if (mode == 1) {
+            const int* q = &rowi[(r + 3) * VO_BLUR_TW + c];
+            int s = 18 * (q[-3 * VO_BLUR_TW] + q[3 * VO_BLUR_TW]) + 34 * (q[-2 * VO_BLUR_TW] + q[2 * VO_BLUR_TW]) +
+                    49 * (q[-VO_BLUR_TW] + q[VO_BLUR_TW]) + 55 * q[0];
+            o = min(max((s + 32768) >> 16, 0), 255);
+        } else {
+            // SymmColumnFilter: s = k0*row[0] + delta; s += k[i]*(row[i] + row[-i])
+            const float* q = &rowf[(r + 3) * VO_BLUR_TW + c];
+            float acc = bk.k[0] * q[0] + 0.f;
+            const float t1 = q[VO_BLUR_TW] + q[-VO_BLUR_TW];
+            const float t2 = q[2 * VO_BLUR_TW] + q[-2 * VO_BLUR_TW];
+            const float t3 = q[3 * VO_BLUR_TW] + q[-3 * VO_BLUR_TW];
+            if (use_fma) {
+                acc = __fmaf_rn(bk.k[1], t1, acc);
+                acc = __fmaf_rn(bk.k[2], t2, acc);
+                acc = __fmaf_rn(bk.k[3], t3, acc);
+            } else {
+                acc = acc + bk.k[1] * t1;
+                acc = acc + bk.k[2] * t2;
+                acc = acc + bk.k[3] * t3;
+            }
+            o = min(max(__float2int_rn(acc), 0), 255);
+        }
+        packed |= (uint32_t)o << (8 * j);
+    }
+    uint8_t* dp = blur + (long)f * g->blur_frame + L.blur_ofs + (long)y * L.bpitch + x0 + c4;
+    *reinterpret_cast<uint32_t*>(dp) = packed;
+}
+
+// ------------------------------------------------------------------ rBRIEF-256, one wavefront per keypoint
+__global__ __launch_bounds__(256) void k_rbrief(const Geom* __restrict__ g, const uint8_t* __restrict__ blur, const signed char* __restrict__ pat_g,
+                                                const int* __restrict__ nkp, const vo_keypoint* __restrict__ kps,
+                                                const uint32_t* __restrict__ kplvl, uint8_t* __restrict__ desc) {
+    __shared__ __attribute__((aligned(16))) signed char pat[1024];
+    const int f = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
+    reinterpret_cast<int*>(pat)[tid] = reinterpret_cast<const int*>(pat_g)[tid];
+    __syncthreads();
+    const int idx = blockIdx.x * 4 + (tid >> 6);
+    if (idx >= nkp[f]) return;
+    const long o = (long)f * g->kp_cap + idx;
+    const uint32_t kl = kplvl[o];
+    const int l = UNPACK_S(kl);
+    const LevelGeom& L = g->lv[l];
+    const uint8_t* center = blur + (long)f * g->blur_frame + L.blur_ofs + (long)UNPACK_Y(kl) * L.bpitch + UNPACK_X(kl);
+    float angle = kps[o].angle;
+    angle *= (float)(M_PI / 180.f);
+    const float a = (float)cos((double)angle), b = (float)sin((double)angle);
+    const int pitch = L.bpitch;
+    uint32_t nib = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const signed char* pp = &pat[(lane * 4 + j) * 4];
+        const float x0 = (float)pp[0], y0 = (float)pp[1], x1 = (float)pp[2], y1 = (float)pp[3];
+        const float xa0 = x0 * a, yb0 = y0 * b, xb0 = x0 * b, ya0 = y0 * a;
+        const float xa1 = x1 * a, yb1 = y1 * b, xb1 = x1 * b, ya1 = y1 * a;
+        const int ix0 = __float2int_rn(xa0 - yb0), iy0 = __float2int_rn(xb0 + ya0);
+        const int ix1 = __float2int_rn(xa1 - yb1), iy1 = __float2int_rn(xb1 + ya1);
+        const int t0 = center[iy0 * pitch + ix0], t1 = center[iy1 * pitch + ix1];
+        nib |= (uint32_t)(t0 < t1) << j;
+    }
+    const uint32_t hi = __shfl_down(nib, 1);
+    if ((lane & 1) == 0) desc[o * 32 + (lane >> 1)] = (uint8_t)(nib | (hi << 4));
+}
+
+// ------------------------------------------------------------------ host: launch the chain
+static void gaussian_kernel7_sigma2(BlurK& bk) {
+    // getGaussianKernel(7, 2, CV_32F) (OpenCV computes it in softdouble)
+    double t[3], sum = 0;
+    const double scale2X = -0.125 / (2.0 * 2.0);
+    for (int i = 0, x = 1 - 7; i < 3; i++, x += 2) {
+        t[i] = std::exp((double)(x * x) * scale2X);
+        sum += t[i];
+    }
+    sum *= 2;
+    sum += 1.0;
+    const double mul1 = 1.0 / sum;
+    bk.k[0] = (float)(1.0 * mul1);
+    bk.k[3] = (float)(t[0] * mul1);
+    bk.k[2] = (float)(t[1] * mul1);
+    bk.k[1] = (float)(t[2] * mul1);
+}
+
+#define STAGE_MARK(c, st, i) \
+    do { if ((c)->timing) (void)hipEventRecord((c)->ev[i], st); } while (0)
+
+int vo_launch_detect(vo_ctx* c, const FrameSrc& src, int F, hipStream_t st) {
+    const Geom& g = c->geom;
+    const Geom* dg = (const Geom*)c->d_geom.p;
+    uint8_t* pyr = (uint8_t*)c->d_pyr.p;
+    uint8_t* blur = (uint8_t*)c->d_blur.p;
+    const TileDesc* tiles = (const TileDesc*)c->d_tiles.p;
+    float* key = (float*)c->d_key.p;
+    uint32_t* payload = (uint32_t*)c->d_payload.p;
+    int* cnt_fast = (int*)c->d_cnt_fast.p;
+    int* cnt_sel1 = (int*)c->d_cnt_sel1.p;
+    int* cnt_sel2 = (int*)c->d_cnt_sel2.p;
+    if (F < 1 || F > c->max_frames) return vo_fail(c, VO_ERR_INVALID, "frame count exceeds the context's chunk size");
+
+    STAGE_MARK(c, st, VO_STAGE_PYRAMID);
+    for (int l = 1; l < g.nlevels; l++) {
+        const LevelGeom& L = g.lv[l];
+        dim3 grid((L.w + 255) / 256, (L.h + 3) / 4, F);
+        hipLaunchKernelGGL(k_pyramid, grid, dim3(256), 0, st, dg, src, pyr, (const ResizeCoef*)c->d_rtab.p, l);
+    }
+    STAGE_MARK(c, st, VO_STAGE_FAST);
+    if (g.ntiles > 0) {
+        hipLaunchKernelGGL(k_fast_tiles, dim3(g.ntiles, F), dim3(256), 0, st, dg, src, pyr, tiles, (uint32_t*)c->d_tile_list.p, (uint8_t*)c->d_seg_cnt.p);
+    }
+    hipLaunchKernelGGL(k_fast_scan, dim3(g.nlevels, F), dim3(256), 0, st, dg, (const uint8_t*)c->d_seg_cnt.p, (uint32_t*)c->d_seg_ofs.p, cnt_fast);
+    if (g.ntiles > 0) {
+        hipLaunchKernelGGL(k_fast_emit, dim3(g.ntiles, F), dim3(64), 0, st, dg, tiles, (const uint32_t*)c->d_tile_list.p, (const uint8_t*)c->d_seg_cnt.p,
+                           (const uint32_t*)c->d_seg_ofs.p, key, payload);
+    }
+    if (c->debug_stop == 1) { HIP_TRY(c, hipGetLastError()); return VO_OK; }
+    STAGE_MARK(c, st, VO_STAGE_SELECT);
+    hipLaunchKernelGGL(k_select<512>, dim3(g.nlevels, F), dim3(512), 0, st, dg, key, payload, (uint32_t*)c->d_lpos.p, (uint32_t*)c->d_rpos.p, cnt_fast, cnt_sel1, 2);
+    hipLaunchKernelGGL(k_harris, dim3(8, g.nlevels, F), dim3(256), 0, st, dg, src, pyr, cnt_sel1, key, payload);
+    if (c->debug_stop == 2) { HIP_TRY(c, hipGetLastError()); return VO_OK; }
+    hipLaunchKernelGGL(k_select<512>, dim3(g.nlevels, F), dim3(512), 0, st, dg, key, payload, (uint32_t*)c->d_lpos.p, (uint32_t*)c->d_rpos.p, cnt_sel1, cnt_sel2, 1);
+    STAGE_MARK(c, st, VO_STAGE_ORIENT);
+    hipLaunchKernelGGL(k_orient, dim3(16, g.nlevels, F), dim3(256), 0, st, dg, src, pyr, cnt_sel2, key, payload, (vo_keypoint*)c->d_kp.p,
+                       (uint32_t*)c->d_kplvl.p, (int*)c->d_nkp.p, (int*)c->d_frame_status.p);
+    STAGE_MARK(c, st, VO_STAGE_BLUR);
+    BlurK bk;
+    gaussian_kernel7_sigma2(bk);
+    hipLaunchKernelGGL(k_blur, dim3(g.nbtiles, F), dim3(256), 0, st, dg, src, pyr, blur, (const TileDesc*)c->d_btiles.p, bk);
+    STAGE_MARK(c, st, VO_STAGE_DESCRIBE);
+    hipLaunchKernelGGL(k_rbrief, dim3((g.kp_cap + 3) / 4, F), dim3(256), 0, st, dg, blur, (const signed char*)c->d_pat.p, (const int*)c->d_nkp.p,
+                       (const vo_keypoint*)c->d_kp.p, (const uint32_t*)c->d_kplvl.p, (uint8_t*)c->d_desc.p);
+    STAGE_MARK(c, st, VO_STAGE_MATCH);
+    HIP_TRY(c, hipGetLastError());
+    return VO_OK;
+}

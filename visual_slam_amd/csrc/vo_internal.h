@@ -1,0 +1,160 @@
+// vo_internal.h -- shared definitions of the MI355X visual-odometry library (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../include/vo_mi355.h"
+
+#define VO_MAX_LEVELS 8
+#define VO_EDGE 31          // runByImageBorder(edgeThreshold)
+#define VO_TILE 32          // FAST tile edge (output pixels)
+#define VO_TILE_CAP 256     // a 32x32 tile holds at most 256 strict 3x3 maxima
+#define VO_BLUR_TW 64
+#define VO_BLUR_TH 16
+
+struct LevelGeom {
+    int w, h, pitch;        // level size; row pitch of the level inside the pyramid slab
+    int quota;              // n_l
+    float scale;            // layerScale[l]
+    long pyr_ofs;           // byte offset of the level in a frame's pyramid slab (level 0 unused)
+    long blur_ofs;          // byte offset in a frame's blurred slab; pitch = bpitch
+    int bpitch;
+    int iw, ih;             // interior (border filtered) region [31, w-31) x [31, h-31); 0 if empty
+    int ntx, nty;           // FAST tiles over the interior
+    int tile_base;          // first tile index of the level inside a frame
+    int seg_base;           // first (row, tile column) segment of the level inside a frame
+    int cand_cap;           // capacity of the level's candidate list
+    long cand_ofs;          // element offset of the level's list inside a frame's candidate arrays
+    int xtab, ytab;         // offsets into the resize coefficient table (level >= 1)
+    int btile_base, bntx, bnty;  // blur tiles
+};
+
+struct Geom {
+    int nlevels, w, h;
+    int ntiles;             // FAST tiles per frame
+    int nsegs;              // segments per frame (padded)
+    int nbtiles;            // blur tiles per frame
+    long pyr_frame;         // bytes per frame in the pyramid slab
+    long blur_frame;        // bytes per frame in the blurred slab
+    long cand_frame;        // candidate elements per frame
+    int kp_cap;             // keypoints per frame (capacity)
+    int fast_threshold, blur_mode, fma;
+    LevelGeom lv[VO_MAX_LEVELS];
+};
+
+struct TileDesc { short level, tx, ty, pad; };
+
+// resize coefficient: source offset and the 8-bit fraction c1 (c0 = 256 - c1)
+struct ResizeCoef { int ofs0, ofs1; int c1; int pad; };
+
+// where a chunk's frames come from: frames [0,nA) are a + i*frame_stride, [nA, ...) are b + ...
+struct FrameSrc {
+    const uint8_t* a;
+    const uint8_t* b;
+    int nA;
+    int pitch;
+    long frame_stride;
+};
+
+__device__ __forceinline__ const uint8_t* frame_ptr(const FrameSrc& s, int f) {
+    return f < s.nA ? s.a + (long)f * s.frame_stride : s.b + (long)(f - s.nA) * s.frame_stride;
+}
+
+// pointer + pitch of unblurred level l of frame f
+__device__ __forceinline__ const uint8_t* level_ptr(const Geom* g, const FrameSrc& s, const uint8_t* pyr, int f, int l, int& pitch) {
+    if (l == 0) {
+        pitch = s.pitch;
+        return frame_ptr(s, f);
+    }
+    pitch = g->lv[l].pitch;
+    return pyr + (long)f * g->pyr_frame + g->lv[l].pyr_ofs;
+}
+
+#define PACK_XYS(x, y, s) ((uint32_t)(x) | ((uint32_t)(y) << 12) | ((uint32_t)(s) << 24))
+#define UNPACK_X(p) ((int)((p) & 0xFFFu))
+#define UNPACK_Y(p) ((int)(((p) >> 12) & 0xFFFu))
+#define UNPACK_S(p) ((int)((p) >> 24))
+
+// ---------------------------------------------------------------- context
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+};
+
+struct vo_ctx {
+    int device = 0;
+    int max_w = 0, max_h = 0, max_frames = 0, chunk_pairs = 0, max_pairs = 0;
+    vo_orb_params params;
+    std::string err;
+    hipStream_t stream = nullptr;  // own stream for the host-pointer entry points
+
+    // geometry currently built (w,h) and its device copies
+    Geom geom;
+    bool geom_valid = false;
+    std::vector<TileDesc> h_tiles, h_btiles;
+    std::vector<ResizeCoef> h_rtab;
+    DevBuf d_geom, d_tiles, d_btiles, d_rtab;
+
+    // per-chunk workspace, sized for max_frames frames of max_w x max_h
+    DevBuf d_img;          // staging for host images
+    DevBuf d_pyr, d_blur;
+    DevBuf d_tile_list, d_seg_cnt, d_seg_ofs;
+    DevBuf d_key, d_payload, d_lpos, d_rpos;
+    DevBuf d_cnt_fast, d_cnt_sel1, d_cnt_sel2;   // int [F][L]
+    DevBuf d_nkp, d_kp, d_kplvl, d_desc, d_frame_status;
+    // matching / pose workspace (per pair)
+    DevBuf d_match;        // int4 [P][kp_cap] best/second per query
+    DevBuf d_nmatch, d_mq, d_q1, d_q2;
+    DevBuf d_pose;         // PoseWork [P]
+    DevBuf d_hyp;          // hypothesis models
+    DevBuf d_mask;
+    DevBuf d_result;       // vo_pair_result [P]
+    DevBuf d_misc;         // small scratch for the single-call entry points
+    DevBuf d_pat;          // rBRIEF pattern (1024 x int8)
+    DevBuf d_pair_status;  // int [max_pairs]
+    DevBuf d_samples, d_nmodels, d_counts, d_vote, d_pair_nkp, d_raw, d_tri;
+    int kp_cap = 0;
+    int debug_stop = 0;    // 0: run everything; 1: stop after FAST emit; 2: stop after retainBest #1 + Harris
+    void* h_pinned = nullptr;
+    size_t h_pinned_bytes = 0;
+
+    // last chunk bookkeeping for vo_debug_read
+    FrameSrc last_src{};
+    int last_frames = 0, last_pairs = 0;
+
+    bool timing = false;
+    float stage_ms[VO_N_STAGES] = {0};
+    hipEvent_t ev[VO_N_STAGES + 1] = {nullptr};
+};
+
+int vo_fail(vo_ctx* c, int code, const std::string& msg);
+#define HIP_TRY(c, expr)                                                                         \
+    do {                                                                                         \
+        hipError_t _e = (expr);                                                                  \
+        if (_e != hipSuccess) return vo_fail((c), VO_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+    } while (0)
+
+// detect.hip
+int vo_build_geometry(vo_ctx* c, int w, int h);
+int vo_launch_detect(vo_ctx* c, const FrameSrc& src, int F, hipStream_t st);
+// match.hip
+int vo_launch_match_impl(vo_ctx* c, int P, int nA, double ratio, int pair0, int4* raw_out, hipStream_t st);
+// pose.hip
+struct PoseK { double fx, fy, cx, cy; };
+// RANSAC (findEssentialMat) for pairs [0,P) of the pair arrays; E/mask/n_inlier left in d_pose / d_mask
+int vo_launch_ransac(vo_ctx* c, int P, const double K[9], double prob, double thr, int max_iters, hipStream_t st);
+// recoverPose for pairs [0,P) using the E in d_pose (or E given per pair by the caller in d_pose)
+int vo_launch_recover(vo_ctx* c, int P, const double K[9], double dist_thresh, hipStream_t st);
+int vo_launch_triangulate(vo_ctx* c, const double* dP, const float* dx1, const float* dx2, int n, float* dX4, hipStream_t st);
+
+#define VO_HYP_ROUND 64   // RANSAC hypotheses solved per round
+struct PoseWork {
+    double E[9];          // best model so far / final
+    double R[9], t[3];    // recoverPose result
+    double R1[9], R2[9], tv[3];
+    unsigned long long rng;
+    int niters, iter, max_good, done;
+    int status, n_good, pad0, pad1;
+};

@@ -1,0 +1,735 @@
+// vo_pose.hip -- five-point RANSAC, recoverPose and DLT triangulation on MI355X (gfx950).
+//
+// Stands behind cv2.findEssentialMat(q1,q2,K,RANSAC,0.999,1.0,None), cv2.recoverPose and
+// cv2.triangulatePoints at /root/reference/libs/vo_utils.py:141,143,160.
+//
+// RANSAC keeps OpenCV's sequential semantics while scoring hypotheses in parallel:
+//   k_ransac_sample  one lane per pair replays cv::RNG(2^64-1) and draws the 5-tuples of
+//                    the next VO_HYP_ROUND iterations (they depend only on the match count);
+//   k_ransac_solve   one lane per (pair, hypothesis): Nister five-point solver in fp64
+//                    (Jacobi SVD null space, 10x20 elimination, degree-10 Durand-Kerner);
+//   k_ransac_score   one wavefront per (pair, hypothesis): float32 Sampson error of every
+//                    match against every model, inlier counts;
+//   k_ransac_scan    one lane per pair walks the (iteration, model) count table in order:
+//                    first strictly better model wins, adaptive niters (RANSACUpdateNumIters).
+// Rounds repeat (host-checked) until every pair's iteration counter reaches its niters.
+// All arithmetic is fp64 (fp32 only where OpenCV casts), compiled with -ffp-contract=off.
+#include <cfloat>
+#include <cmath>
+
+#include "vo_internal.h"
+
+// ------------------------------------------------------------------ cv::RNG
+struct DevRNG {
+    unsigned long long state;
+    __device__ unsigned next() {
+        state = (unsigned long long)(unsigned)state * 4164903690u + (unsigned)(state >> 32);
+        return (unsigned)state;
+    }
+    __device__ int uniform(int a, int b) { return a == b ? a : (int)(next() % (unsigned)(b - a) + a); }
+};
+
+// ------------------------------------------------------------------ JacobiSVDImpl_<double>
+// One-sided Jacobi on the N rows (length M) of At; Vt (N x N) accumulates the rotations;
+// rows N..N1-1 are completed with RNG(0x12345678) as OpenCV does for FULL_UV.
+template <int M, int N, int N1>
+__device__ void jacobi_svd(double* At, double* W, double* Vt) {
+    const double minval = DBL_MIN, eps = DBL_EPSILON * 10;
+    const int max_iter = M > 30 ? M : 30;
+    double c, s, sd;
+    for (int i = 0; i < N; i++) {
+        sd = 0;
+        for (int k = 0; k < M; k++) { double t = At[i * M + k]; sd += t * t; }
+        W[i] = sd;
+        for (int k = 0; k < N; k++) Vt[i * N + k] = 0;
+        Vt[i * N + i] = 1;
+    }
+    for (int iter = 0; iter < max_iter; iter++) {
+        bool changed = false;
+        for (int i = 0; i < N - 1; i++)
+            for (int j = i + 1; j < N; j++) {
+                double *Ai = At + i * M, *Aj = At + j * M;
+                double a = W[i], p = 0, b = W[j];
+                for (int k = 0; k < M; k++) p += Ai[k] * Aj[k];
+                if (fabs(p) <= eps * sqrt(a * b)) continue;
+                p *= 2;
+                double beta = a - b, gamma = sqrt(p * p + beta * beta);
+                if (beta < 0) {
+                    double delta = (gamma - beta) * 0.5;
+                    s = sqrt(delta / gamma);
+                    c = p / (gamma * s * 2);
+                } else {
+                    c = sqrt((gamma + beta) / (gamma * 2));
+                    s = p / (gamma * c * 2);
+                }
+                a = b = 0;
+                for (int k = 0; k < M; k++) {
+                    double t0 = c * Ai[k] + s * Aj[k];
+                    double t1 = -s * Ai[k] + c * Aj[k];
+                    Ai[k] = t0; Aj[k] = t1;
+                    a += t0 * t0; b += t1 * t1;
+                }
+                W[i] = a; W[j] = b;
+                changed = true;
+                double *Vi = Vt + i * N, *Vj = Vt + j * N;
+                for (int k = 0; k < N; k++) {
+                    double t0 = c * Vi[k] + s * Vj[k];
+                    double t1 = -s * Vi[k] + c * Vj[k];
+                    Vi[k] = t0; Vj[k] = t1;
+                }
+            }
+        if (!changed) break;
+    }
+    for (int i = 0; i < N; i++) {
+        sd = 0;
+        for (int k = 0; k < M; k++) { double t = At[i * M + k]; sd += t * t; }
+        W[i] = sqrt(sd);
+    }
+    for (int i = 0; i < N - 1; i++) {
+        int j = i;
+        for (int k = i + 1; k < N; k++)
+            if (W[j] < W[k]) j = k;
+        if (i != j) {
+            double t = W[i]; W[i] = W[j]; W[j] = t;
+            for (int k = 0; k < M; k++) { t = At[i * M + k]; At[i * M + k] = At[j * M + k]; At[j * M + k] = t; }
+            for (int k = 0; k < N; k++) { t = Vt[i * N + k]; Vt[i * N + k] = Vt[j * N + k]; Vt[j * N + k] = t; }
+        }
+    }
+    DevRNG rng{0x12345678ull};
+    for (int i = 0; i < N1; i++) {
+        sd = i < N ? W[i] : 0;
+        for (int ii = 0; ii < 100 && sd <= minval; ii++) {
+            const double val0 = 1. / M;
+            for (int k = 0; k < M; k++) At[i * M + k] = (rng.next() & 256) != 0 ? val0 : -val0;
+            for (int iter = 0; iter < 2; iter++)
+                for (int j = 0; j < i; j++) {
+                    sd = 0;
+                    for (int k = 0; k < M; k++) sd += At[i * M + k] * At[j * M + k];
+                    double asum = 0;
+                    for (int k = 0; k < M; k++) {
+                        double t = At[i * M + k] - sd * At[j * M + k];
+                        At[i * M + k] = t;
+                        asum += fabs(t);
+                    }
+                    asum = asum > eps * 100 ? 1 / asum : 0;
+                    for (int k = 0; k < M; k++) At[i * M + k] *= asum;
+                }
+            sd = 0;
+            for (int k = 0; k < M; k++) { double t = At[i * M + k]; sd += t * t; }
+            sd = sqrt(sd);
+        }
+        s = sd > minval ? 1 / sd : 0.;
+        for (int k = 0; k < M; k++) At[i * M + k] *= s;
+    }
+}
+
+// SVD::compute of a square MxM matrix: U, W, Vt row-major
+template <int M>
+__device__ void svd_square(const double* A, double* W, double* U, double* Vt) {
+    double At[M * M];
+    for (int i = 0; i < M; i++)
+        for (int j = 0; j < M; j++) At[i * M + j] = A[j * M + i];
+    jacobi_svd<M, M, M>(At, W, Vt);
+    for (int i = 0; i < M; i++)
+        for (int j = 0; j < M; j++) U[i * M + j] = At[j * M + i];
+}
+
+// ------------------------------------------------------------------ polynomials in (x,y,z), degree <= 3
+struct Poly3 { double c[4][4][4]; };
+__device__ void pzero(Poly3& r) {
+    for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) for (int k = 0; k < 4; k++) r.c[i][j][k] = 0;
+}
+// r = a*b (degrees da, db)
+__device__ void pmul(Poly3& r, const Poly3& a, int da, const Poly3& b, int db) {
+    pzero(r);
+    for (int i = 0; i <= da; i++)
+        for (int j = 0; i + j <= da; j++)
+            for (int k = 0; i + j + k <= da; k++) {
+                const double av = a.c[i][j][k];
+                if (av == 0) continue;
+                for (int p = 0; p <= db; p++)
+                    for (int q = 0; p + q <= db; q++)
+                        for (int s = 0; p + q + s <= db; s++) r.c[i + p][j + q][k + s] += av * b.c[p][q][s];
+            }
+}
+// r = a + sb*b
+__device__ void padd(Poly3& r, const Poly3& a, const Poly3& b, double sb) {
+    for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) for (int k = 0; k < 4; k++) r.c[i][j][k] = a.c[i][j][k] + sb * b.c[i][j][k];
+}
+__constant__ signed char c_mono[20][3] = {{3, 0, 0}, {0, 3, 0}, {2, 1, 0}, {1, 2, 0}, {2, 0, 1}, {2, 0, 0}, {0, 2, 1}, {0, 2, 0}, {1, 1, 1}, {1, 1, 0},
+                                          {1, 0, 2}, {1, 0, 1}, {1, 0, 0}, {0, 1, 2}, {0, 1, 1}, {0, 1, 0}, {0, 0, 3}, {0, 0, 2}, {0, 0, 1}, {0, 0, 0}};
+
+struct Cx { double re, im; };
+__device__ __forceinline__ Cx cmul(Cx a, Cx b) { return Cx{a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
+__device__ __forceinline__ Cx cadd(Cx a, Cx b) { return Cx{a.re + b.re, a.im + b.im}; }
+__device__ __forceinline__ Cx csub(Cx a, Cx b) { return Cx{a.re - b.re, a.im - b.im}; }
+__device__ __forceinline__ Cx cdiv(Cx a, Cx b) {
+    double t = 1. / (b.re * b.re + b.im * b.im);
+    return Cx{(a.re * b.re + a.im * b.im) * t, (-a.re * b.im + a.im * b.re) * t};
+}
+
+#define DK_T 64  // threads per solver workgroup; LDS arrays are [index][thread]
+
+// cv::solvePoly(coeffs, roots, 300): Durand-Kerner, in-place updates, start (1+i)^k.
+// coef/rre/rim point at this thread's column of the LDS arrays (stride DK_T).
+__device__ void solve_poly10(const double* coeffs_in, double* coef, double* rre, double* rim) {
+    int n = 10;
+    for (int i = 0; i <= 10; i++) coef[i * DK_T] = coeffs_in[i];
+    for (; n > 1; n--)
+        if (fabs(coef[n * DK_T]) > DBL_EPSILON) break;
+    Cx p{1, 0};
+    const Cx r{1, 1};
+    for (int i = 0; i < n; i++) {
+        rre[i * DK_T] = p.re; rim[i * DK_T] = p.im;
+        p = cmul(p, r);
+    }
+    const double lead = coef[n * DK_T];
+    for (int iter = 0; iter < 300; iter++) {
+        double maxDiff = 0;
+        for (int i = 0; i < n; i++) {
+            p = Cx{rre[i * DK_T], rim[i * DK_T]};
+            Cx num{lead, 0}, denom{lead, 0};
+            int num_same_root = 1;
+            for (int j = 0; j < n; j++) {
+                num = cadd(cmul(num, p), Cx{coef[(n - j - 1) * DK_T], 0});
+                if (j != i) {
+                    Cx d = csub(p, Cx{rre[j * DK_T], rim[j * DK_T]});
+                    if (d.re != 0 || d.im != 0) denom = cmul(denom, d);
+                    else num_same_root++;
+                }
+            }
+            num = cdiv(num, denom);
+            if (num_same_root > 1 && (num_same_root % 2) == 0) {
+                const double old_re = num.re, old_im = num.im;
+                const int times = num_same_root / 2;
+                for (int j = 0; j < times; j++) {
+                    num.re = old_re * old_re + old_im * old_im;
+                    num.re = sqrt(num.re);
+                    num.re += old_re;
+                    num.im = num.re - old_re;
+                    num.re /= 2;
+                    num.re = sqrt(num.re);
+                    num.im /= 2;
+                    num.im = sqrt(num.im);
+                    if (old_re < 0) num.im = -num.im;
+                }
+            }
+            rre[i * DK_T] = p.re - num.re;
+            rim[i * DK_T] = p.im - num.im;
+            maxDiff = fmax(maxDiff, sqrt(num.re * num.re + num.im * num.im));
+        }
+        if (maxDiff <= 0) break;
+    }
+    for (int i = 0; i < n; i++)
+        if (fabs(rim[i * DK_T]) < 1e-100) rim[i * DK_T] = 0;
+    for (; n < 10; n++) { rre[n * DK_T] = rre[(n - 1) * DK_T]; rim[n * DK_T] = rim[(n - 1) * DK_T]; }
+}
+
+// EMEstimatorCallback::runKernel.  x1,x2: 5 normalised correspondences.  Writes up to 10
+// models (row-major, unit Frobenius norm, x2^T E x1 = 0) to Ebuf; returns their number.
+__device__ int five_point(const double* x1, const double* x2, double* Ebuf, double* coef, double* rre, double* rim) {
+    double At[9 * 9];
+    for (int i = 0; i < 81; i++) At[i] = 0;
+    for (int i = 0; i < 5; i++) {
+        const double u1 = x1[2 * i], v1 = x1[2 * i + 1], u2 = x2[2 * i], v2 = x2[2 * i + 1];
+        double* q = At + i * 9;
+        q[0] = u2 * u1; q[1] = u2 * v1; q[2] = u2;
+        q[3] = v2 * u1; q[4] = v2 * v1; q[5] = v2;
+        q[6] = u1;      q[7] = v1;      q[8] = 1.0;
+    }
+    double W[5], V[25];
+    jacobi_svd<9, 5, 9>(At, W, V);
+    const double* EE0 = At + 5 * 9;  // 4 null-space vectors, consecutive rows
+
+    Poly3 Ep[3][3];
+    for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 3; c++) {
+            pzero(Ep[r][c]);
+            Ep[r][c].c[1][0][0] = EE0[0 * 9 + r * 3 + c];
+            Ep[r][c].c[0][1][0] = EE0[1 * 9 + r * 3 + c];
+            Ep[r][c].c[0][0][1] = EE0[2 * 9 + r * 3 + c];
+            Ep[r][c].c[0][0][0] = EE0[3 * 9 + r * 3 + c];
+        }
+    Poly3 EEt[3][3], tmp, tmp2;
+    for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 3; c++) {
+            Poly3 s;
+            pzero(s);
+            for (int k = 0; k < 3; k++) {
+                pmul(tmp, Ep[r][k], 1, Ep[c][k], 1);
+                padd(s, s, tmp, 1.0);
+            }
+            EEt[r][c] = s;
+        }
+    Poly3 tr;
+    padd(tr, EEt[0][0], EEt[1][1], 1.0);
+    padd(tr, tr, EEt[2][2], 1.0);
+    double A[10][20];
+    auto store_eq = [&](int e, const Poly3& q) {
+        for (int m = 0; m < 20; m++) A[e][m] = q.c[c_mono[m][0]][c_mono[m][1]][c_mono[m][2]];
+    };
+    {
+        Poly3 m0, m1, m2, d;
+        pmul(tmp, Ep[1][1], 1, Ep[2][2], 1); pmul(tmp2, Ep[1][2], 1, Ep[2][1], 1); padd(m0, tmp, tmp2, -1.0);
+        pmul(tmp, Ep[1][0], 1, Ep[2][2], 1); pmul(tmp2, Ep[1][2], 1, Ep[2][0], 1); padd(m1, tmp, tmp2, -1.0);
+        pmul(tmp, Ep[1][0], 1, Ep[2][1], 1); pmul(tmp2, Ep[1][1], 1, Ep[2][0], 1); padd(m2, tmp, tmp2, -1.0);
+        pmul(d, Ep[0][0], 1, m0, 2);
+        pmul(tmp, Ep[0][1], 1, m1, 2); padd(d, d, tmp, -1.0);
+        pmul(tmp, Ep[0][2], 1, m2, 2); padd(d, d, tmp, 1.0);
+        store_eq(0, d);
+    }
+    for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 3; c++) {
+            Poly3 s;
+            pzero(s);
+            for (int k = 0; k < 3; k++) {
+                pmul(tmp, EEt[r][k], 2, Ep[k][c], 1);
+                padd(s, s, tmp, 2.0);
+            }
+            pmul(tmp, tr, 2, Ep[r][c], 1);
+            padd(s, s, tmp, -1.0);
+            store_eq(1 + r * 3 + c, s);
+        }
+    for (int col = 0; col < 10; col++) {
+        int piv = col;
+        double best = fabs(A[col][col]);
+        for (int r = col + 1; r < 10; r++)
+            if (fabs(A[r][col]) > best) { best = fabs(A[r][col]); piv = r; }
+        if (best < DBL_MIN) return 0;
+        if (piv != col)
+            for (int m = 0; m < 20; m++) { double t = A[piv][m]; A[piv][m] = A[col][m]; A[col][m] = t; }
+        const double inv = 1.0 / A[col][col];
+        for (int m = col; m < 20; m++) A[col][m] *= inv;
+        for (int r = 0; r < 10; r++) {
+            if (r == col) continue;
+            const double f = A[r][col];
+            if (f == 0) continue;
+            for (int m = col; m < 20; m++) A[r][m] -= f * A[col][m];
+        }
+    }
+    double b[3][13];
+    for (int i = 0; i < 3; i++) {
+        const double* a1 = &A[i * 2 + 4][10];
+        const double* a2 = &A[i * 2 + 5][10];
+        double row1[13], row2[13];
+        for (int k = 0; k < 13; k++) { row1[k] = 0; row2[k] = 0; }
+        for (int k = 0; k < 3; k++) { row1[1 + k] = a1[k]; row1[5 + k] = a1[3 + k]; }
+        for (int k = 0; k < 4; k++) row1[9 + k] = a1[6 + k];
+        for (int k = 0; k < 3; k++) { row2[k] = a2[k]; row2[4 + k] = a2[3 + k]; }
+        for (int k = 0; k < 4; k++) row2[8 + k] = a2[6 + k];
+        for (int k = 0; k < 13; k++) b[i][k] = row1[k] - row2[k];
+    }
+    double P[3][3][5];
+    for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 3; c++) {
+            for (int k = 0; k < 5; k++) P[r][c][k] = 0;
+            if (c < 2) for (int k = 0; k < 4; k++) P[r][c][3 - k] = b[r][c * 4 + k];
+            else for (int k = 0; k < 5; k++) P[r][c][4 - k] = b[r][8 + k];
+        }
+    double cdet[11];
+    for (int k = 0; k <= 10; k++) cdet[k] = 0;
+    for (int r = 0; r < 3; r++) {
+        const int r0 = (r == 0) ? 1 : 0, r1 = (r == 2) ? 1 : 2;
+        double m_a[7], m_b[7], minor[7], term[11];
+        for (int k = 0; k < 7; k++) { m_a[k] = 0; m_b[k] = 0; }
+        for (int i = 0; i <= 3; i++)
+            for (int j = 0; j <= 3; j++) { m_a[i + j] += P[r0][0][i] * P[r1][1][j]; }
+        for (int i = 0; i <= 3; i++)
+            for (int j = 0; j <= 3; j++) { m_b[i + j] += P[r0][1][i] * P[r1][0][j]; }
+        for (int k = 0; k < 7; k++) minor[k] = m_a[k] - m_b[k];
+        for (int k = 0; k <= 10; k++) term[k] = 0;
+        for (int i = 0; i <= 4; i++)
+            for (int j = 0; j <= 6; j++) term[i + j] += P[r][2][i] * minor[j];
+        const double sgn = (r == 1) ? -1.0 : 1.0;
+        for (int k = 0; k <= 10; k++) cdet[k] += sgn * term[k];
+    }
+    solve_poly10(cdet, coef, rre, rim);
+    int count = 0;
+    for (int i = 0; i < 10; i++) {
+        if (fabs(rim[i * DK_T]) > 1e-10) continue;
+        const double z1 = rre[i * DK_T], z2 = z1 * z1, z3 = z2 * z1, z4 = z3 * z1;
+        double bz[9];
+        for (int j = 0; j < 3; j++) {
+            const double* br = b[j];
+            bz[j * 3 + 0] = br[0] * z3 + br[1] * z2 + br[2] * z1 + br[3];
+            bz[j * 3 + 1] = br[4] * z3 + br[5] * z2 + br[6] * z1 + br[7];
+            bz[j * 3 + 2] = br[8] * z4 + br[9] * z3 + br[10] * z2 + br[11] * z1 + br[12];
+        }
+        double w3[3], U3[9], Vt3[9];
+        svd_square<3>(bz, w3, U3, Vt3);
+        const double* xy1 = Vt3 + 6;
+        if (fabs(xy1[2]) < 1e-10) continue;
+        const double xs = xy1[0] / xy1[2], ys = xy1[1] / xy1[2], zs = z1;
+        double* E = Ebuf + count * 9;
+        double nrm = 0;
+        for (int k = 0; k < 9; k++) {
+            E[k] = EE0[0 * 9 + k] * xs + EE0[1 * 9 + k] * ys + EE0[2 * 9 + k] * zs + EE0[3 * 9 + k];
+            nrm += E[k] * E[k];
+        }
+        nrm = sqrt(nrm);
+        for (int k = 0; k < 9; k++) E[k] /= nrm;
+        count++;
+    }
+    return count;
+}
+
+// (col - c)/f as the MatExpr col*(1/f) + (-c*(1/f))
+struct NormK { double ax, bx, ay, by; };
+__device__ __forceinline__ void norm_pt(const NormK& nk, float2 q, double& x, double& y) {
+    x = (double)q.x * nk.ax + nk.bx;
+    y = (double)q.y * nk.ay + nk.by;
+}
+
+__device__ __forceinline__ float sampson_err(const double* E, double u1, double v1, double u2, double v2) {
+    const double e0 = E[0] * u1 + E[1] * v1 + E[2], e1 = E[3] * u1 + E[4] * v1 + E[5], e2 = E[6] * u1 + E[7] * v1 + E[8];
+    const double f0 = E[0] * u2 + E[3] * v2 + E[6], f1 = E[1] * u2 + E[4] * v2 + E[7];
+    const double x2tEx1 = u2 * e0 + v2 * e1 + e2;
+    const double a = e0 * e0, b = e1 * e1, c = f0 * f0, d = f1 * f1;
+    return (float)(x2tEx1 * x2tEx1 / (a + b + c + d));
+}
+
+__device__ int ransac_update_num_iters(double p, double ep, int modelPoints, int maxIters) {
+    p = fmax(p, 0.); p = fmin(p, 1.);
+    ep = fmax(ep, 0.); ep = fmin(ep, 1.);
+    double num = fmax(1. - p, DBL_MIN);
+    double denom = 1. - pow(1. - ep, (double)modelPoints);
+    if (denom < DBL_MIN) return 0;
+    num = log(num);
+    denom = log(denom);
+    return denom >= 0 || -num >= maxIters * (-denom) ? maxIters : (int)rint(num / denom);
+}
+
+// ------------------------------------------------------------------ RANSAC kernels
+__global__ void k_ransac_init(PoseWork* pw, const int* __restrict__ nmatch, const int* __restrict__ pair_status, int P, int max_iters) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    PoseWork& w = pw[p];
+    w.rng = 0xFFFFFFFFFFFFFFFFull;
+    w.niters = max_iters > 1 ? max_iters : 1;
+    w.iter = 0;
+    w.max_good = 0;
+    w.n_good = 0;
+    const int n = nmatch[p];
+    w.status = pair_status[p];
+    w.done = 0;
+    if (w.status != VO_OK) w.done = 1;
+    else if (n < 5) { w.status = VO_ERR_TOO_FEW; w.done = 1; }
+    for (int i = 0; i < 9; i++) w.E[i] = 0;
+}
+
+// draw the 5-tuples of iterations [iter, iter+VO_HYP_ROUND) of every active pair
+__global__ void k_ransac_sample(PoseWork* pw, const int* __restrict__ nmatch, int P, int* __restrict__ samples) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    PoseWork& w = pw[p];
+    if (w.done) return;
+    const int n = nmatch[p];
+    DevRNG rng{w.rng};
+    int* sp = samples + (long)p * VO_HYP_ROUND * 5;
+    for (int h = 0; h < VO_HYP_ROUND; h++) {
+        int idx[5];
+        if (n == 5) {
+            for (int i = 0; i < 5; i++) idx[i] = i;
+        } else {
+            for (int i = 0; i < 5; i++) {
+                int v;
+                bool dup;
+                do {
+                    v = rng.uniform(0, n);
+                    dup = false;
+                    for (int j = 0; j < i; j++) dup |= (idx[j] == v);
+                } while (dup);
+                idx[i] = v;
+            }
+        }
+        for (int i = 0; i < 5; i++) sp[h * 5 + i] = idx[i];
+    }
+    w.rng = rng.state;
+}
+
+__global__ __launch_bounds__(DK_T) void k_ransac_solve(const PoseWork* __restrict__ pw, const int* __restrict__ nmatch, int P, int kp_cap,
+                                                       const float2* __restrict__ q1, const float2* __restrict__ q2, NormK nk,
+                                                       const int* __restrict__ samples, double* __restrict__ models, int* __restrict__ nmodels) {
+    __shared__ double s_coef[11 * DK_T], s_rre[10 * DK_T], s_rim[10 * DK_T];
+    const int p = blockIdx.y, h = blockIdx.x * DK_T + threadIdx.x;
+    const PoseWork& w = pw[p];
+    if (w.done) return;
+    if (h >= VO_HYP_ROUND) return;
+    const long ho = (long)p * VO_HYP_ROUND + h;
+    if (w.iter + h >= w.niters) { nmodels[ho] = 0; return; }   // beyond the current budget: never consumed
+    const int* sp = samples + ho * 5;
+    double x1[10], x2[10];
+    for (int i = 0; i < 5; i++) {
+        const long o = (long)p * kp_cap + sp[i];
+        norm_pt(nk, q1[o], x1[2 * i], x1[2 * i + 1]);
+        norm_pt(nk, q2[o], x2[2 * i], x2[2 * i + 1]);
+    }
+    double Eb[90];
+    const int nm = five_point(x1, x2, Eb, s_coef + threadIdx.x, s_rre + threadIdx.x, s_rim + threadIdx.x);
+    nmodels[ho] = nm;
+    double* mo = models + ho * 90;
+    for (int i = 0; i < nm * 9; i++) mo[i] = Eb[i];
+}
+
+// one wavefront per (pair, hypothesis): inlier count of each of its models
+__global__ __launch_bounds__(256) void k_ransac_score(const PoseWork* __restrict__ pw, const int* __restrict__ nmatch, int P, int kp_cap,
+                                                      const float2* __restrict__ q1, const float2* __restrict__ q2, NormK nk, float thr2,
+                                                      const double* __restrict__ models, const int* __restrict__ nmodels, int* __restrict__ counts) {
+    const int p = blockIdx.y, h = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (pw[p].done || h >= VO_HYP_ROUND) return;
+    const long ho = (long)p * VO_HYP_ROUND + h;
+    const int nm = nmodels[ho];
+    if (nm <= 0) return;
+    const int n = nmatch[p];
+    int cnt[10];
+    for (int m = 0; m < 10; m++) cnt[m] = 0;
+    const double* mo = models + ho * 90;
+    for (int i = lane; i < n; i += 64) {
+        const long o = (long)p * kp_cap + i;
+        double u1, v1, u2, v2;
+        norm_pt(nk, q1[o], u1, v1);
+        norm_pt(nk, q2[o], u2, v2);
+        for (int m = 0; m < nm; m++) cnt[m] += sampson_err(mo + m * 9, u1, v1, u2, v2) <= thr2 ? 1 : 0;
+    }
+    for (int m = 0; m < nm; m++) {
+        int c = cnt[m];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+        if (lane == 0) counts[ho * 10 + m] = c;
+    }
+}
+
+// sequential semantics of RANSACPointSetRegistrator::run over this round's hypotheses
+__global__ void k_ransac_scan(PoseWork* pw, const int* __restrict__ nmatch, int P, double prob, const double* __restrict__ models,
+                              const int* __restrict__ nmodels, const int* __restrict__ counts, int* __restrict__ active) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    PoseWork& w = pw[p];
+    if (w.done) return;
+    const int n = nmatch[p];
+    int niters = w.niters, maxGood = w.max_good, iter = w.iter;
+    if (n == 5) {
+        // count == modelPoints: the kernel runs once, all points are inliers
+        const long ho = (long)p * VO_HYP_ROUND;
+        if (nmodels[ho] <= 0) { w.status = VO_ERR_NO_MODEL; }
+        else { for (int i = 0; i < 9; i++) w.E[i] = models[ho * 90 + i]; w.max_good = 5; }
+        w.done = 1;
+        return;
+    }
+    int h = 0;
+    for (; h < VO_HYP_ROUND && iter < niters; h++, iter++) {
+        const long ho = (long)p * VO_HYP_ROUND + h;
+        const int nm = nmodels[ho];
+        for (int m = 0; m < nm; m++) {
+            const int good = counts[ho * 10 + m];
+            if (good > max(maxGood, 4)) {
+                for (int i = 0; i < 9; i++) w.E[i] = models[ho * 90 + m * 9 + i];
+                maxGood = good;
+                niters = ransac_update_num_iters(prob, (double)(n - good) / n, 5, niters);
+            }
+        }
+    }
+    w.niters = niters; w.max_good = maxGood; w.iter = iter;
+    if (!(iter < niters)) {
+        w.done = 1;
+        if (maxGood <= 0) w.status = VO_ERR_NO_MODEL;
+    } else {
+        atomicAdd(active, 1);
+    }
+}
+
+// inlier mask of the winning model (same arithmetic as the scoring pass)
+__global__ __launch_bounds__(256) void k_ransac_mask(const PoseWork* __restrict__ pw, const int* __restrict__ nmatch, int kp_cap,
+                                                     const float2* __restrict__ q1, const float2* __restrict__ q2, NormK nk, float thr2,
+                                                     uint8_t* __restrict__ mask) {
+    const int p = blockIdx.y;
+    const int n = nmatch[p];
+    const PoseWork& w = pw[p];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const long o = (long)p * kp_cap + i;
+    uint8_t f = 0;
+    if (w.status == VO_OK) {
+        if (n == 5) f = 1;
+        else {
+            double u1, v1, u2, v2;
+            norm_pt(nk, q1[o], u1, v1);
+            norm_pt(nk, q2[o], u2, v2);
+            f = sampson_err(w.E, u1, v1, u2, v2) <= thr2 ? 1 : 0;
+        }
+    }
+    mask[o] = f;
+}
+
+// ------------------------------------------------------------------ recoverPose
+__device__ double det3(const double* M) {
+    return M[0] * (M[4] * M[8] - M[5] * M[7]) - M[1] * (M[3] * M[8] - M[5] * M[6]) + M[2] * (M[3] * M[7] - M[4] * M[6]);
+}
+__device__ void mat3mul(const double* A, const double* B, double* C) {
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) {
+            double s = 0;
+            for (int k = 0; k < 3; k++) s += A[i * 3 + k] * B[k * 3 + j];
+            C[i * 3 + j] = s;
+        }
+}
+
+// decomposeEssentialMat per pair
+__global__ void k_decompose(PoseWork* pw, int P, int* __restrict__ vote) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    PoseWork& w = pw[p];
+    for (int c = 0; c < 4; c++) vote[p * 4 + c] = 0;
+    if (w.status != VO_OK) return;
+    double D[3], U[9], Vt[9], E[9];
+    for (int i = 0; i < 9; i++) E[i] = w.E[i];
+    svd_square<3>(E, D, U, Vt);
+    if (det3(U) < 0) for (int i = 0; i < 9; i++) U[i] *= -1.;
+    if (det3(Vt) < 0) for (int i = 0; i < 9; i++) Vt[i] *= -1.;
+    const double Wm[9] = {0, 1, 0, -1, 0, 0, 0, 0, 1}, Wt[9] = {0, -1, 0, 1, 0, 0, 0, 0, 1};
+    double tmp[9], R1[9], R2[9];
+    mat3mul(U, Wm, tmp); mat3mul(tmp, Vt, R1);
+    mat3mul(U, Wt, tmp); mat3mul(tmp, Vt, R2);
+    for (int i = 0; i < 9; i++) { w.R1[i] = R1[i]; w.R2[i] = R2[i]; }
+    for (int i = 0; i < 3; i++) w.tv[i] = U[i * 3 + 2];
+}
+
+__device__ void triangulate_one(const double* P1, const double* P2, double x1, double y1, double x2, double y2, double X[4]) {
+    double A[16];
+    for (int k = 0; k < 4; k++) {
+        A[0 * 4 + k] = x1 * P1[8 + k] - P1[0 + k];
+        A[1 * 4 + k] = y1 * P1[8 + k] - P1[4 + k];
+        A[2 * 4 + k] = x2 * P2[8 + k] - P2[0 + k];
+        A[3 * 4 + k] = y2 * P2[8 + k] - P2[4 + k];
+    }
+    double W[4], U[16], Vt[16];
+    svd_square<4>(A, W, U, Vt);
+    for (int k = 0; k < 4; k++) X[k] = Vt[12 + k];
+}
+
+// cheirality vote: one lane per (pair, match, candidate pose)
+__global__ __launch_bounds__(256) void k_cheirality(const PoseWork* __restrict__ pw, const int* __restrict__ nmatch, int kp_cap,
+                                                    const float2* __restrict__ q1, const float2* __restrict__ q2, NormK nk, double dist_thresh,
+                                                    int* __restrict__ vote) {
+    const int p = blockIdx.y, c = blockIdx.z;
+    const PoseWork& w = pw[p];
+    if (w.status != VO_OK) return;
+    const int n = nmatch[p];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    int m = 0;
+    if (i < n) {
+        const double* Rc = (c & 1) ? w.R2 : w.R1;
+        const double sg = (c >= 2) ? -1.0 : 1.0;
+        double Pm[12];
+        for (int r = 0; r < 3; r++) {
+            for (int j = 0; j < 3; j++) Pm[r * 4 + j] = Rc[r * 3 + j];
+            Pm[r * 4 + 3] = sg * w.tv[r];
+        }
+        const double P0[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+        const long o = (long)p * kp_cap + i;
+        double u1, v1, u2, v2, Q[4];
+        norm_pt(nk, q1[o], u1, v1);
+        norm_pt(nk, q2[o], u2, v2);
+        triangulate_one(P0, Pm, u1, v1, u2, v2, Q);
+        bool ok = (Q[2] * Q[3]) > 0;
+        Q[0] /= Q[3]; Q[1] /= Q[3]; Q[2] /= Q[3]; Q[3] /= Q[3];
+        ok = ok && (Q[2] < dist_thresh);
+        const double z = Pm[8] * Q[0] + Pm[9] * Q[1] + Pm[10] * Q[2] + Pm[11] * Q[3];
+        ok = ok && (z > 0) && (z < dist_thresh);
+        m = ok ? 1 : 0;
+    }
+    const unsigned long long b = __ballot(m);
+    if ((threadIdx.x & 63) == 0 && b) atomicAdd(&vote[p * 4 + c], (int)__popcll(b));
+}
+
+__global__ void k_pose_pick(PoseWork* pw, int P, const int* __restrict__ vote) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    PoseWork& w = pw[p];
+    if (w.status != VO_OK) return;
+    const int g0 = vote[p * 4], g1 = vote[p * 4 + 1], g2 = vote[p * 4 + 2], g3 = vote[p * 4 + 3];
+    int sel;
+    if (g0 >= g1 && g0 >= g2 && g0 >= g3) sel = 0;
+    else if (g1 >= g0 && g1 >= g2 && g1 >= g3) sel = 1;
+    else if (g2 >= g0 && g2 >= g1 && g2 >= g3) sel = 2;
+    else sel = 3;
+    const double* Rs = (sel & 1) ? w.R2 : w.R1;
+    for (int i = 0; i < 9; i++) w.R[i] = Rs[i];
+    for (int i = 0; i < 3; i++) w.t[i] = (sel >= 2 ? -1.0 : 1.0) * w.tv[i];
+    w.n_good = sel == 0 ? g0 : sel == 1 ? g1 : sel == 2 ? g2 : g3;
+}
+
+// ------------------------------------------------------------------ triangulatePoints (float32 in/out)
+__global__ __launch_bounds__(256) void k_triangulate(const double* __restrict__ Pm, const float* __restrict__ x1, const float* __restrict__ x2,
+                                                     int n, float* __restrict__ X4) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    double P1[12], P2[12], X[4];
+    for (int k = 0; k < 12; k++) { P1[k] = Pm[k]; P2[k] = Pm[12 + k]; }
+    triangulate_one(P1, P2, (double)x1[2 * i], (double)x1[2 * i + 1], (double)x2[2 * i], (double)x2[2 * i + 1], X);
+    for (int k = 0; k < 4; k++) X4[(long)k * n + i] = (float)X[k];
+}
+
+// ------------------------------------------------------------------ host
+static NormK make_normk(const double K[9]) {
+    const double fx = K[0], fy = K[4], cx = K[2], cy = K[5];
+    NormK nk;
+    nk.ax = 1. / fx; nk.bx = -cx * (1. / fx);
+    nk.ay = 1. / fy; nk.by = -cy * (1. / fy);
+    return nk;
+}
+
+int vo_launch_ransac(vo_ctx* c, int P, const double K[9], double prob, double thr, int max_iters, hipStream_t st) {
+    if (P < 1 || P > c->max_pairs) return vo_fail(c, VO_ERR_INVALID, "pair count exceeds max_pairs");
+    const int kp_cap = c->kp_cap;
+    const NormK nk = make_normk(K);
+    const double threshold = thr / ((K[0] + K[4]) / 2);
+    const float thr2 = (float)(threshold * threshold);
+    PoseWork* pw = (PoseWork*)c->d_pose.p;
+    const int* nmatch = (const int*)c->d_nmatch.p;
+    const float2* q1 = (const float2*)c->d_q1.p;
+    const float2* q2 = (const float2*)c->d_q2.p;
+    int* samples = (int*)c->d_samples.p;
+    double* models = (double*)c->d_hyp.p;
+    int* nmodels = (int*)c->d_nmodels.p;
+    int* counts = (int*)c->d_counts.p;
+    int* active = (int*)c->d_misc.p;
+    const int pb = (P + 63) / 64;
+    hipLaunchKernelGGL(k_ransac_init, dim3(pb), dim3(64), 0, st, pw, nmatch, (const int*)c->d_pair_status.p, P, max_iters);
+    const int max_rounds = (std::max(max_iters, 1) + VO_HYP_ROUND - 1) / VO_HYP_ROUND;
+    for (int round = 0; round < max_rounds; round++) {
+        HIP_TRY(c, hipMemsetAsync(active, 0, sizeof(int), st));
+        hipLaunchKernelGGL(k_ransac_sample, dim3(pb), dim3(64), 0, st, pw, nmatch, P, samples);
+        hipLaunchKernelGGL(k_ransac_solve, dim3(VO_HYP_ROUND / DK_T, P), dim3(DK_T), 0, st, pw, nmatch, P, kp_cap, q1, q2, nk, samples, models, nmodels);
+        hipLaunchKernelGGL(k_ransac_score, dim3(VO_HYP_ROUND / 4, P), dim3(256), 0, st, pw, nmatch, P, kp_cap, q1, q2, nk, thr2, models, nmodels, counts);
+        hipLaunchKernelGGL(k_ransac_scan, dim3(pb), dim3(64), 0, st, pw, nmatch, P, prob, models, nmodels, counts, active);
+        int h_active = 0;
+        HIP_TRY(c, hipMemcpyAsync(&h_active, active, sizeof(int), hipMemcpyDeviceToHost, st));
+        HIP_TRY(c, hipStreamSynchronize(st));
+        if (h_active == 0) break;
+    }
+    hipLaunchKernelGGL(k_ransac_mask, dim3((kp_cap + 255) / 256, P), dim3(256), 0, st, pw, nmatch, kp_cap, q1, q2, nk, thr2, (uint8_t*)c->d_mask.p);
+    HIP_TRY(c, hipGetLastError());
+    return VO_OK;
+}
+
+int vo_launch_recover(vo_ctx* c, int P, const double K[9], double dist_thresh, hipStream_t st) {
+    if (P < 1 || P > c->max_pairs) return vo_fail(c, VO_ERR_INVALID, "pair count exceeds max_pairs");
+    const int kp_cap = c->kp_cap;
+    const NormK nk = make_normk(K);
+    PoseWork* pw = (PoseWork*)c->d_pose.p;
+    int* vote = (int*)c->d_vote.p;
+    const int pb = (P + 63) / 64;
+    hipLaunchKernelGGL(k_decompose, dim3(pb), dim3(64), 0, st, pw, P, vote);
+    hipLaunchKernelGGL(k_cheirality, dim3((kp_cap + 255) / 256, P, 4), dim3(256), 0, st, pw, (const int*)c->d_nmatch.p, kp_cap,
+                       (const float2*)c->d_q1.p, (const float2*)c->d_q2.p, nk, dist_thresh, vote);
+    hipLaunchKernelGGL(k_pose_pick, dim3(pb), dim3(64), 0, st, pw, P, vote);
+    HIP_TRY(c, hipGetLastError());
+    return VO_OK;
+}
+
+int vo_launch_triangulate(vo_ctx* c, const double* dP, const float* dx1, const float* dx2, int n, float* dX4, hipStream_t st) {
+    hipLaunchKernelGGL(k_triangulate, dim3((n + 255) / 256), dim3(256), 0, st, dP, dx1, dx2, n, dX4);
+    HIP_TRY(c, hipGetLastError());
+    return VO_OK;
+}
