@@ -1,0 +1,153 @@
+"""GPU parity of matcher, RANSAC, recoverPose, triangulation and the whole pair path
+against the CPU oracle, through the C ABI."""
+import os
+
+import numpy as np
+import pytest
+
+from test_oracle_pose import two_view, rot_angle, dir_angle
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from visual_slam_amd import _lib
+    c = _lib.Context(max_w=1241, max_h=376, chunk_pairs=2, max_pairs=4)
+    yield c
+    c.close()
+
+
+def test_match_knn2_bit_exact(ctx, oracle):
+    rng = np.random.default_rng(1)
+    for nq, nt in [(300, 257), (3000, 2973), (1, 2), (65, 4000), (4024, 4024)]:
+        q = rng.integers(0, 256, (nq, 32), dtype=np.uint8)
+        t = rng.integers(0, 256, (nt, 32), dtype=np.uint8)
+        if nt > 210 and nq > 5:
+            t[10] = t[200]; q[5] = t[10]   # exact ties: lower train index first
+        got = ctx.match_knn2(q, t)
+        ref = oracle.match_knn2(q, t)
+        for a, b in zip(got, ref):
+            assert np.array_equal(a, b), (nq, nt)
+
+
+def test_match_on_real_descriptors_and_ratio(ctx, oracle, kitti02):
+    k1, f1 = oracle.orb_detect_compute(kitti02[0])
+    k2, f2 = oracle.orb_detect_compute(kitti02[1])
+    i1, d1, i2, d2 = oracle.match_knn2(f1, f2)
+    for ratio in (0.45, 0.7, 1.0):
+        keep = oracle.ratio_filter(d1, d2, ratio)
+        qi, ti, a, b = ctx.match_knn2_ratio(f1, f2, ratio)
+        assert np.array_equal(qi, keep) and np.array_equal(ti, i1[keep])
+        assert np.array_equal(a, d1[keep]) and np.array_equal(b, d2[keep])
+
+
+def test_match_errors(ctx):
+    from visual_slam_amd._lib import VoError, VO_ERR_TOO_FEW, VO_ERR_CAPACITY
+    q = np.zeros((10, 32), np.uint8)
+    with pytest.raises(VoError) as e:
+        ctx.match_knn2(q, q[:1])
+    assert e.value.code == VO_ERR_TOO_FEW
+    with pytest.raises(VoError) as e:
+        ctx.match_knn2(np.zeros((5000, 32), np.uint8), q)
+    assert e.value.code == VO_ERR_CAPACITY
+    assert len(ctx.match_knn2_ratio(np.zeros((0, 32), np.uint8), q)[0]) == 0
+
+
+def test_ransac_matches_oracle(ctx, oracle, K02):
+    for seed, n, noise, outl in [(0, 200, 0.0, 0), (3, 400, 0.3, 120), (5, 900, 0.5, 500), (6, 50, 0.2, 10)]:
+        x1, x2, R, t, _ = two_view(seed, n, K02, noise=noise, outliers=outl)
+        Eo, mo, no, iters = oracle.find_essential_ransac(x1, x2, K02)
+        E, m, ni = ctx.find_essential_ransac(x1, x2, K02)
+        assert ni == no and np.array_equal(m, mo), (seed, iters)
+        assert np.abs(E - Eo).max() < 1e-9
+        Ro, to, go = oracle.recover_pose(Eo, x1, x2, K02)
+        Rg, tg, gg = ctx.recover_pose(E, x1, x2, K02)
+        assert gg == go
+        assert rot_angle(Ro, Rg) < 1e-6 and dir_angle(to, tg) < 1e-6   # north-star bound is 1e-3 rad
+
+
+def test_ransac_degenerate_counts(ctx, oracle, K02):
+    from visual_slam_amd._lib import VoError, VO_ERR_TOO_FEW
+    x1, x2, *_ = two_view(0, 4, K02)
+    with pytest.raises(VoError) as e:
+        ctx.find_essential_ransac(x1, x2, K02)
+    assert e.value.code == VO_ERR_TOO_FEW
+    x1, x2, *_ = two_view(0, 5, K02)
+    E, mask, ninl = ctx.find_essential_ransac(x1, x2, K02)
+    Eo, mo, no, _ = oracle.find_essential_ransac(x1, x2, K02)
+    assert ninl == 5 and mask.all() and np.abs(E - Eo).max() < 1e-9
+
+
+def test_ransac_many_iterations(ctx, oracle, K02):
+    """Low inlier ratio: several rounds of 64 hypotheses, adaptive stopping must agree."""
+    x1, x2, *_ = two_view(11, 300, K02, noise=0.2, outliers=200)
+    Eo, mo, no, iters = oracle.find_essential_ransac(x1, x2, K02)
+    assert iters > 64
+    E, m, ni = ctx.find_essential_ransac(x1, x2, K02)
+    assert ni == no and np.array_equal(m, mo) and np.abs(E - Eo).max() < 1e-9
+
+
+def test_triangulate_matches_oracle(ctx, oracle, K02):
+    x1, x2, R, t, X = two_view(2, 777, K02, noise=0.1)
+    P1 = K02 @ np.eye(4)[:3]
+    P2 = K02 @ np.c_[R, t]
+    Xo = oracle.triangulate_f32(P1, P2, x1, x2)
+    Xg = ctx.triangulate(P1, P2, x1, x2)
+    po = (Xo / Xo[3])[:3]; pg = (Xg / Xg[3])[:3]
+    assert np.abs(po - pg).max() / np.abs(po).max() < 1e-5   # north-star: relative error below 1e-5
+    assert np.abs(np.abs(Xo) - np.abs(Xg)).max() < 1e-6
+
+
+def test_pairs_run_matches_oracle(ctx, oracle, kitti02, kitti09, K02):
+    from visual_slam_amd import _lib as L
+    A = np.stack([kitti02[0], kitti02[1], kitti02[2]])
+    B = np.stack([kitti02[1], kitti02[2], kitti02[3]])
+    res = ctx.pairs_run(A, B, K02)
+    for i in range(3):
+        rc, T, counts = oracle.pair_run(A[i], B[i], K02)
+        r = res[i]
+        assert rc == 0 and r["status"] == 0
+        assert [r["n_kp1"], r["n_kp2"], r["n_match"], r["n_inlier"]] == counts.tolist()
+        assert rot_angle(T[:3, :3], r["T"][:3, :3]) < 1e-6 and dir_angle(T[:3, 3], r["T"][:3, 3]) < 1e-6
+        assert np.array_equal(r["T"][3], [0, 0, 0, 1])
+    # match indices are bit exact too (host-image path stages chunk_pairs=2 at a time: pair 2 is index 0 of the last batch)
+    k1, f1 = oracle.orb_detect_compute(A[2]); k2, f2 = oracle.orb_detect_compute(B[2])
+    i1, d1, i2, d2 = oracle.match_knn2(f1, f2)
+    keep = oracle.ratio_filter(d1, d2, 0.45)
+    mq = ctx.debug_read(L.VO_DBG_MATCHES, 0, 0, np.int32).reshape(-1, 4)
+    assert np.array_equal(mq[:, 0], keep) and np.array_equal(mq[:, 1], i1[keep])
+
+
+def test_pairs_run_reports_failures_per_pair(ctx, kitti02, K02):
+    from visual_slam_amd._lib import VO_ERR_TOO_FEW
+    flat = np.full_like(kitti02[0], 90)
+    res = ctx.pairs_run(np.stack([kitti02[0], flat]), np.stack([kitti02[1], flat]), K02)
+    assert res[0]["status"] == 0 and res[1]["status"] == VO_ERR_TOO_FEW
+    assert res[1]["n_kp1"] == 0 and not res[1]["T"].any()
+
+
+def test_dropin_visual_odometry(oracle, K02):
+    """The reference's call sequence (vo.py:74-93) through the drop-in class."""
+    from conftest import GOLDEN
+    from visual_slam_amd import VisualOdometry
+    vo = VisualOdometry(os.path.join(GOLDEN, "kitti02"), False)
+    assert np.allclose(vo.K, K02) and vo.D.shape == (5,) and len(vo.image_paths) == 4 and len(vo.gt_poses) == 4
+    q1, q2 = vo.get_matches(1, "ORB", None, None)
+    assert q1.dtype == np.float32 and q1.shape == q2.shape and q1.shape[1] == 2
+    transf = np.nan_to_num(vo.get_pose(q1, q2), neginf=0, posinf=0)
+    from conftest import load_gray
+    rc, T, counts = oracle.pair_run(load_gray(vo.image_paths[0]), load_gray(vo.image_paths[1]), K02)
+    assert len(q1) == counts[2]
+    assert rot_angle(T[:3, :3], transf[:3, :3]) < 1e-6 and dir_angle(T[:3, 3], transf[:3, 3]) < 1e-6
+    prev_pose = np.eye(4); cur_pose = prev_pose @ np.linalg.inv(transf)
+    p = vo.triangulate(q1[0], q2[0], prev_pose, cur_pose)
+    assert p.shape == (3,) and p.dtype == np.float32
+    pb = vo.triangulate(q1, q2, prev_pose, cur_pose)
+    assert pb.shape == (len(q1), 3) and np.allclose(pb[0], p, rtol=1e-6)
+    P1 = vo.K @ prev_pose[:3]; P2 = vo.K @ cur_pose[:3]
+    Xo = oracle.triangulate_f32(P1, P2, q1, q2)
+    ref = (Xo / Xo[3])[:3].T
+    assert np.abs(pb - ref).max() / np.abs(ref).max() < 1e-5
+    with pytest.raises(NotImplementedError):
+        vo.get_matches(1, "SIFT", None, None)
