@@ -1,0 +1,163 @@
+#!/usr/bin/env python3
+"""bench.py -- frame-pairs/sec (detect + match + pose) at 1241x376 / 3000 ORB features.
+
+One "step" = one pass of the hot path (vo_pairs_run_device: ORB detect x2, Hamming 2-NN +
+ratio, five-point RANSAC, recoverPose) over a batch of B synthetic frame pairs per GPU
+(BASELINE.json configs[2]: a batch of configs[1]-style pairs, seeds rank*B .. rank*B+B-1),
+already resident in HBM when the timed region starts.  Pairs are independent, so ranks
+shard them with no data-path collective ("weak" scaling: B per GPU is fixed).
+
+Contract: python bench.py --gpus N --steps K --warmup W   (N>1 under torch.distributed.run)
+prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+W_IMG, H_IMG, NFEAT = 1241, 376, 3000
+# algorithmic HBM bytes per frame; per-launch figures are these x frames per launch
+PYR_PX = [1241 * 376, 1034 * 313, 862 * 261, 718 * 218, 598 * 181, 499 * 151, 416 * 126, 346 * 105]
+P_TOTAL = sum(PYR_PX)  # 1,444,097
+ALGO_BYTES_PER_FRAME = {
+    "k_pyramid": P_TOTAL,                      # read level 0 + write levels 1..7 (all 7 launches together)
+    "k_fast_tiles": P_TOTAL,                   # read every pyramid pixel once
+    "k_blur": 2 * P_TOTAL,                     # read + write every pyramid pixel
+    "k_rbrief": NFEAT * 512 + NFEAT * 32,
+    "k_orient": NFEAT * 749,
+    "k_harris": 2 * NFEAT * 81,
+}
+HBM_PEAK_GBS = 8000.0
+# matcher: 16 lane-ops (8 xor + 8 popcount) per distance; peak = 256 CU x 4 SIMD x 32 lanes x 2.4 GHz
+VALU_PEAK_TOPS = 256 * 4 * 32 * 2.4e9 / 1e12
+
+
+def cpu_baseline(imgsA, imgsB, K, budget_s=12.0):
+    """The CPU oracle (a port of the cv2 path, oracle/) timed on this host, one core,
+    on a bounded sample of the same pairs."""
+    from oracle import oracle as O
+    O.build()
+    n = 0
+    t0 = time.perf_counter()
+    while n < len(imgsA) and (time.perf_counter() - t0 < budget_s or n < 2):
+        rc, _, _ = O.pair_run(imgsA[n], imgsB[n], K)
+        n += 1
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "frame-pairs/sec", "cores": 1, "kind": "port",
+            "sample": "first %d pairs of rank 0's batch, scalar C++ oracle (restated cv2 ORB+BFMatcher+findEssentialMat+recoverPose), 1 thread" % n}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--pairs", type=int, default=256, help="frame pairs per GPU per step")
+    ap.add_argument("--chunk", type=int, default=32, help="pairs per detect/match launch wave")
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    from visual_slam_amd import _lib, synth
+
+    B = args.pairs
+    workers = max(1, min(16, (os.cpu_count() or 1) // max(world, 1)))
+    imgsA, imgsB = synth.make_batch(range(rank * B, rank * B + B), W_IMG, H_IMG, workers=workers)
+    K = synth.K_KITTI02
+    dA = torch.from_numpy(imgsA).cuda()
+    dB = torch.from_numpy(imgsB).cuda()
+    ctx = _lib.Context(max_w=W_IMG, max_h=H_IMG, chunk_pairs=min(args.chunk, B), max_pairs=B, device=local_rank)
+
+    def step():
+        return ctx.pairs_run_device(dA.data_ptr(), dB.data_ptr(), B, W_IMG, H_IMG, W_IMG, K)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    res = None
+    for _ in range(args.warmup):
+        res = step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ok = int((res["status"] == 0).sum())
+
+    # per-kernel durations: HIP events around every launch on the launch stream (diagnostic pass,
+    # outside the timed region)
+    roofline = None
+    kernels = {}
+    if rank == 0:
+        ctx.set_kernel_timing(True)
+        step()
+        kt = ctx.kernel_timing()
+        ctx.set_kernel_timing(False)
+        frames_per_launch = 2 * min(args.chunk, B)
+        for name, (ms, n) in kt.items():
+            if n:
+                kernels[name] = {"ms_total": round(ms, 4), "launches": n, "avg_ms": round(ms / n, 5)}
+        # dominant HBM-bound kernel = the one of the byte-streaming kernels with the largest total time
+        hbm = {k: v for k, v in kernels.items() if k in ("k_pyramid", "k_fast_tiles", "k_blur")}
+        dom = max(hbm, key=lambda k: hbm[k]["ms_total"])
+        launches_per_pass = 7 if dom == "k_pyramid" else 1
+        bytes_per_launch = ALGO_BYTES_PER_FRAME[dom] * frames_per_launch / launches_per_pass
+        avg_s = hbm[dom]["avg_ms"] * 1e-3
+        achieved = bytes_per_launch / avg_s / 1e9
+        roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                    "bytes_per_launch": int(bytes_per_launch), "avg_launch_ms": hbm[dom]["avg_ms"]}
+        if "k_match" in kernels:
+            nk = res["n_kp1"].astype(np.float64) * res["n_kp2"].astype(np.float64)
+            ops = float(nk.sum()) * 16.0
+            roofline["matcher"] = {"bound": "valu-int", "achieved_Tlaneops": round(ops / (kernels["k_match"]["ms_total"] * 1e-3) / 1e12, 3),
+                                   "peak_Tlaneops": round(VALU_PEAK_TOPS, 2)}
+
+    cpu = None
+    if rank == 0 and not args.no_cpu:
+        cpu = cpu_baseline(imgsA, imgsB, K)
+
+    if rank == 0:
+        value = world * B * args.steps / dt
+        out = {
+            "metric": "frame-pairs/sec (detect+match+pose) at 1241x376/3k ORB",
+            "value": round(value, 2), "unit": "frame-pairs/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8/int32 detect+match, f64 pose", "data": "synthetic",
+            "config": {"workload": "configs[2]: batch of synthetic 1241x376 pairs (configs[1] generator, seeds 0..), 3000 ORB features, 8 levels",
+                       "pairs_per_gpu": B, "global_pairs": world * B, "chunk_pairs": min(args.chunk, B), "parallelism": "pairs sharded over ranks, no collective",
+                       "pairs_ok": ok},
+            "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -135,20 +135,28 @@ long vo_debug_read(vo_ctx* ctx, int what, int index, int level, void* out, long 
  * 2 = stop after retainBest #1 + Harris. */
 int vo_set_debug_stop(vo_ctx* ctx, int stage);
 
-/* Timing of the last vo_pairs_run_device call, measured with HIP events on the stream
- * the kernels were launched on: stage_ms[VO_N_STAGES] and launches per stage.  Only
- * collected when enabled (it adds event records between stages). */
-#define VO_N_STAGES 8
-#define VO_STAGE_PYRAMID 0
-#define VO_STAGE_FAST 1
-#define VO_STAGE_SELECT 2    /* both retainBest passes + Harris */
-#define VO_STAGE_ORIENT 3
-#define VO_STAGE_BLUR 4
-#define VO_STAGE_DESCRIBE 5
-#define VO_STAGE_MATCH 6
-#define VO_STAGE_POSE 7
-int vo_set_stage_timing(vo_ctx* ctx, int enable);
-int vo_get_stage_timing(vo_ctx* ctx, float stage_ms[VO_N_STAGES]);
+/* Per-kernel timing of the vo_pairs_run_device calls made while it is enabled, measured with
+ * HIP events recorded around every launch on the stream the kernels are launched on
+ * (diagnostic mode: it serialises the launches).  ms[k] = summed duration, launches[k] =
+ * number of launches of kernel k since timing was enabled.  VO_K_RANSAC / VO_K_RECOVER
+ * bracket the whole multi-kernel stage. */
+#define VO_N_KERNELS 14
+#define VO_K_PYRAMID 0
+#define VO_K_FAST_TILES 1
+#define VO_K_FAST_SCAN 2
+#define VO_K_FAST_EMIT 3
+#define VO_K_SELECT1 4
+#define VO_K_HARRIS 5
+#define VO_K_SELECT2 6
+#define VO_K_ORIENT 7
+#define VO_K_BLUR 8
+#define VO_K_RBRIEF 9
+#define VO_K_MATCH 10
+#define VO_K_RATIO 11
+#define VO_K_RANSAC 12
+#define VO_K_RECOVER 13
+int vo_set_kernel_timing(vo_ctx* ctx, int enable);
+int vo_get_kernel_timing(vo_ctx* ctx, float ms[VO_N_KERNELS], int32_t launches[VO_N_KERNELS]);
 
 #ifdef __cplusplus
 }

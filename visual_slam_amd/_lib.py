@@ -15,8 +15,9 @@ VO_OK, VO_ERR_INVALID, VO_ERR_HIP, VO_ERR_CAPACITY, VO_ERR_TOO_FEW, VO_ERR_NO_MO
 
 VO_DBG_PYR_LEVEL, VO_DBG_BLUR_LEVEL, VO_DBG_FAST_LIST, VO_DBG_SEL1_LIST, VO_DBG_SEL1_HARRIS = 1, 2, 3, 4, 5
 VO_DBG_KEYPOINTS, VO_DBG_DESCRIPTORS, VO_DBG_MATCHES, VO_DBG_E_MASK = 6, 7, 8, 9
-VO_N_STAGES = 8
-STAGE_NAMES = ["pyramid", "fast", "select", "orient", "blur", "describe", "match", "pose"]
+VO_N_KERNELS = 14
+KERNEL_NAMES = ["k_pyramid", "k_fast_tiles", "k_fast_scan", "k_fast_emit", "k_select#1", "k_harris", "k_select#2", "k_orient",
+                "k_blur", "k_rbrief", "k_match", "k_ratio", "ransac(stage)", "recover_pose(stage)"]
 
 
 class OrbParams(C.Structure):
@@ -34,7 +35,7 @@ PAIR_DTYPE = np.dtype([("T", "<f8", (4, 4)), ("n_kp1", "<i4"), ("n_kp2", "<i4"),
 EXPORTS = [
     "vo_default_orb_params", "vo_ctx_create", "vo_ctx_destroy", "vo_last_error", "vo_orb_detect_compute", "vo_match_knn2_ratio",
     "vo_match_knn2", "vo_find_essential_ransac", "vo_recover_pose", "vo_triangulate", "vo_pairs_run_device", "vo_pairs_run",
-    "vo_debug_read", "vo_set_debug_stop", "vo_set_stage_timing", "vo_get_stage_timing",
+    "vo_debug_read", "vo_set_debug_stop", "vo_set_kernel_timing", "vo_get_kernel_timing",
 ]
 
 _lib = None
@@ -66,8 +67,8 @@ def load():
     lib.vo_debug_read.argtypes = [vp, i, i, i, vp, C.c_long]
     lib.vo_debug_read.restype = C.c_long
     lib.vo_set_debug_stop.argtypes = [vp, i]
-    lib.vo_set_stage_timing.argtypes = [vp, i]
-    lib.vo_get_stage_timing.argtypes = [vp, vp]
+    lib.vo_set_kernel_timing.argtypes = [vp, i]
+    lib.vo_get_kernel_timing.argtypes = [vp, vp, vp]
     _lib = lib
     return lib
 
@@ -192,13 +193,14 @@ class Context:
     def set_debug_stop(self, stage):
         self._check(self.lib.vo_set_debug_stop(self.h, stage))
 
-    def set_stage_timing(self, enable):
-        self._check(self.lib.vo_set_stage_timing(self.h, int(enable)))
+    def set_kernel_timing(self, enable):
+        self._check(self.lib.vo_set_kernel_timing(self.h, int(enable)))
 
-    def stage_timing(self):
-        ms = np.zeros(VO_N_STAGES, np.float32)
-        self._check(self.lib.vo_get_stage_timing(self.h, _ptr(ms)))
-        return dict(zip(STAGE_NAMES, ms.tolist()))
+    def kernel_timing(self):
+        """{kernel name: (total ms, launches)} since timing was enabled."""
+        ms = np.zeros(VO_N_KERNELS, np.float32); n = np.zeros(VO_N_KERNELS, np.int32)
+        self._check(self.lib.vo_get_kernel_timing(self.h, _ptr(ms), _ptr(n)))
+        return {k: (float(a), int(b)) for k, a, b in zip(KERNEL_NAMES, ms, n)}
 
     def debug_read(self, what, index, level=0, dtype=np.uint8):
         n = self.lib.vo_debug_read(self.h, what, index, level, None, 0)

@@ -12,6 +12,34 @@ int vo_fail(vo_ctx* c, int code, const std::string& msg) {
     return code;
 }
 
+// ---- per-kernel timing: events recorded around a launch on the launch stream
+void kt_begin(vo_ctx* c, hipStream_t st, int id) {
+    if (!c->timing) return;
+    const size_t i = c->ev_ids.size();
+    while (c->ev_pool.size() < 2 * (i + 1)) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) { c->timing = false; return; }
+        c->ev_pool.push_back(e);
+    }
+    c->ev_ids.push_back(id);
+    (void)hipEventRecord(c->ev_pool[2 * i], st);
+}
+void kt_end(vo_ctx* c, hipStream_t st) {
+    if (!c->timing || c->ev_ids.empty()) return;
+    (void)hipEventRecord(c->ev_pool[2 * (c->ev_ids.size() - 1) + 1], st);
+}
+int kt_collect(vo_ctx* c) {
+    for (size_t i = 0; i < c->ev_ids.size(); i++) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, c->ev_pool[2 * i], c->ev_pool[2 * i + 1]) == hipSuccess) {
+            c->kernel_ms[c->ev_ids[i]] += ms;
+            c->kernel_launches[c->ev_ids[i]] += 1;
+        }
+    }
+    c->ev_ids.clear();
+    return VO_OK;
+}
+
 static int dev_alloc(vo_ctx* c, DevBuf& b, size_t bytes) {
     bytes = std::max<size_t>(bytes, 256);
     HIP_TRY(c, hipMalloc(&b.p, bytes));
@@ -69,7 +97,6 @@ static int ctx_init(vo_ctx* c) {
     const vo_orb_params& p = c->params;
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    for (int i = 0; i <= VO_N_STAGES; i++) HIP_TRY(c, hipEventCreate(&c->ev[i]));
     c->kp_cap = p.nfeatures + 1024;
     const long F = c->max_frames, kc = c->kp_cap, MP = c->max_pairs, CP = c->chunk_pairs;
     // geometry-sized buffers: size them for the largest image with a dry geometry pass
@@ -174,8 +201,7 @@ void vo_ctx_destroy(vo_ctx* c) {
                       &c->d_hyp, &c->d_mask, &c->d_result, &c->d_misc, &c->d_pat, &c->d_pair_status, &c->d_samples, &c->d_nmodels, &c->d_counts,
                       &c->d_vote, &c->d_pair_nkp, &c->d_raw, &c->d_tri};
     for (DevBuf* b : bufs) dev_free(*b);
-    for (int i = 0; i <= VO_N_STAGES; i++)
-        if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+    for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -188,14 +214,16 @@ int vo_set_debug_stop(vo_ctx* c, int stage) {
     return VO_OK;
 }
 
-int vo_set_stage_timing(vo_ctx* c, int enable) {
+int vo_set_kernel_timing(vo_ctx* c, int enable) {
     if (!c) return VO_ERR_INVALID;
     c->timing = enable != 0;
+    for (int i = 0; i < VO_N_KERNELS; i++) { c->kernel_ms[i] = 0; c->kernel_launches[i] = 0; }
+    c->ev_ids.clear();
     return VO_OK;
 }
-int vo_get_stage_timing(vo_ctx* c, float stage_ms[VO_N_STAGES]) {
-    if (!c || !stage_ms) return VO_ERR_INVALID;
-    for (int i = 0; i < VO_N_STAGES; i++) stage_ms[i] = c->stage_ms[i];
+int vo_get_kernel_timing(vo_ctx* c, float ms[VO_N_KERNELS], int32_t launches[VO_N_KERNELS]) {
+    if (!c || !ms || !launches) return VO_ERR_INVALID;
+    for (int i = 0; i < VO_N_KERNELS; i++) { ms[i] = c->kernel_ms[i]; launches[i] = c->kernel_launches[i]; }
     return VO_OK;
 }
 
@@ -216,6 +244,7 @@ int vo_orb_detect_compute(vo_ctx* c, const uint8_t* img, int w, int h, int strid
     HIP_TRY(c, hipMemcpyAsync(&hn[0], c->d_nkp.p, 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(c, hipMemcpyAsync(&hn[1], c->d_frame_status.p, 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(c, hipStreamSynchronize(st));
+    if (c->timing) kt_collect(c);
     if (c->debug_stop) { *n = 0; return VO_OK; }
     if (hn[1] != VO_OK) return vo_fail(c, hn[1], "vo_orb_detect_compute: keypoint list overflow (too many response ties)");
     *n = hn[0];
@@ -379,7 +408,6 @@ int vo_pairs_run_device(vo_ctx* c, const uint8_t* imgsA, const uint8_t* imgsB, i
     if (rc != VO_OK) return rc;
     hipStream_t st = stream ? (hipStream_t)stream : c->stream;
     const long fs = (long)stride * h;
-    if (c->timing) for (int i = 0; i < VO_N_STAGES; i++) c->stage_ms[i] = 0;
     for (int b0 = 0; b0 < B; b0 += c->max_pairs) {
         const int Pb = std::min(c->max_pairs, B - b0);
         for (int p0 = 0; p0 < Pb; p0 += c->chunk_pairs) {
@@ -391,31 +419,24 @@ int vo_pairs_run_device(vo_ctx* c, const uint8_t* imgsA, const uint8_t* imgsB, i
             rc = vo_launch_match_impl(c, Pc, Pc, ratio, p0, nullptr, st);
             if (rc != VO_OK) return rc;
             if (c->timing) {
-                HIP_TRY(c, hipEventRecord(c->ev[VO_STAGE_POSE], st));
                 HIP_TRY(c, hipStreamSynchronize(st));
-                for (int s = 0; s < VO_STAGE_POSE; s++) {
-                    float ms = 0;
-                    HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[s], c->ev[s + 1]));
-                    c->stage_ms[s] += ms;
-                }
+                kt_collect(c);
             }
         }
         c->last_pairs = Pb;
-        if (c->timing) HIP_TRY(c, hipEventRecord(c->ev[VO_STAGE_POSE], st));
+        kt_begin(c, st, VO_K_RANSAC);
         rc = vo_launch_ransac(c, Pb, K, 0.999, 1.0, 1000, st);
+        kt_end(c, st);
         if (rc != VO_OK) return rc;
+        kt_begin(c, st, VO_K_RECOVER);
         rc = vo_launch_recover(c, Pb, K, 50.0, st);
+        kt_end(c, st);
         if (rc != VO_OK) return rc;
         hipLaunchKernelGGL(k_results, dim3((Pb + 63) / 64), dim3(64), 0, st, (const PoseWork*)c->d_pose.p, (const int*)c->d_nmatch.p,
                            (const int2*)c->d_pair_nkp.p, Pb, (vo_pair_result*)c->d_result.p);
-        if (c->timing) HIP_TRY(c, hipEventRecord(c->ev[VO_N_STAGES], st));
         HIP_TRY(c, hipMemcpyAsync(out + b0, c->d_result.p, (size_t)Pb * sizeof(vo_pair_result), hipMemcpyDeviceToHost, st));
         HIP_TRY(c, hipStreamSynchronize(st));
-        if (c->timing) {
-            float ms = 0;
-            HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[VO_STAGE_POSE], c->ev[VO_N_STAGES]));
-            c->stage_ms[VO_STAGE_POSE] += ms;
-        }
+        if (c->timing) kt_collect(c);
     }
     return VO_OK;
 }

@@ -821,9 +821,6 @@ static void gaussian_kernel7_sigma2(BlurK& bk) {
     bk.k[1] = (float)(t[2] * mul1);
 }
 
-#define STAGE_MARK(c, st, i) \
-    do { if ((c)->timing) (void)hipEventRecord((c)->ev[i], st); } while (0)
-
 int vo_launch_detect(vo_ctx* c, const FrameSrc& src, int F, hipStream_t st) {
     const Geom& g = c->geom;
     const Geom* dg = (const Geom*)c->d_geom.p;
@@ -837,38 +834,31 @@ int vo_launch_detect(vo_ctx* c, const FrameSrc& src, int F, hipStream_t st) {
     int* cnt_sel2 = (int*)c->d_cnt_sel2.p;
     if (F < 1 || F > c->max_frames) return vo_fail(c, VO_ERR_INVALID, "frame count exceeds the context's chunk size");
 
-    STAGE_MARK(c, st, VO_STAGE_PYRAMID);
     for (int l = 1; l < g.nlevels; l++) {
         const LevelGeom& L = g.lv[l];
         dim3 grid((L.w + 255) / 256, (L.h + 3) / 4, F);
-        hipLaunchKernelGGL(k_pyramid, grid, dim3(256), 0, st, dg, src, pyr, (const ResizeCoef*)c->d_rtab.p, l);
+        KT(c, st, VO_K_PYRAMID, hipLaunchKernelGGL(k_pyramid, grid, dim3(256), 0, st, dg, src, pyr, (const ResizeCoef*)c->d_rtab.p, l));
     }
-    STAGE_MARK(c, st, VO_STAGE_FAST);
     if (g.ntiles > 0) {
-        hipLaunchKernelGGL(k_fast_tiles, dim3(g.ntiles, F), dim3(256), 0, st, dg, src, pyr, tiles, (uint32_t*)c->d_tile_list.p, (uint8_t*)c->d_seg_cnt.p);
+        KT(c, st, VO_K_FAST_TILES, hipLaunchKernelGGL(k_fast_tiles, dim3(g.ntiles, F), dim3(256), 0, st, dg, src, pyr, tiles, (uint32_t*)c->d_tile_list.p, (uint8_t*)c->d_seg_cnt.p));
     }
-    hipLaunchKernelGGL(k_fast_scan, dim3(g.nlevels, F), dim3(256), 0, st, dg, (const uint8_t*)c->d_seg_cnt.p, (uint32_t*)c->d_seg_ofs.p, cnt_fast);
+    KT(c, st, VO_K_FAST_SCAN, hipLaunchKernelGGL(k_fast_scan, dim3(g.nlevels, F), dim3(256), 0, st, dg, (const uint8_t*)c->d_seg_cnt.p, (uint32_t*)c->d_seg_ofs.p, cnt_fast));
     if (g.ntiles > 0) {
-        hipLaunchKernelGGL(k_fast_emit, dim3(g.ntiles, F), dim3(64), 0, st, dg, tiles, (const uint32_t*)c->d_tile_list.p, (const uint8_t*)c->d_seg_cnt.p,
-                           (const uint32_t*)c->d_seg_ofs.p, key, payload);
+        KT(c, st, VO_K_FAST_EMIT, hipLaunchKernelGGL(k_fast_emit, dim3(g.ntiles, F), dim3(64), 0, st, dg, tiles, (const uint32_t*)c->d_tile_list.p, (const uint8_t*)c->d_seg_cnt.p,
+                           (const uint32_t*)c->d_seg_ofs.p, key, payload));
     }
     if (c->debug_stop == 1) { HIP_TRY(c, hipGetLastError()); return VO_OK; }
-    STAGE_MARK(c, st, VO_STAGE_SELECT);
-    hipLaunchKernelGGL(k_select<512>, dim3(g.nlevels, F), dim3(512), 0, st, dg, key, payload, (uint32_t*)c->d_lpos.p, (uint32_t*)c->d_rpos.p, cnt_fast, cnt_sel1, 2);
-    hipLaunchKernelGGL(k_harris, dim3(8, g.nlevels, F), dim3(256), 0, st, dg, src, pyr, cnt_sel1, key, payload);
+    KT(c, st, VO_K_SELECT1, hipLaunchKernelGGL(k_select<512>, dim3(g.nlevels, F), dim3(512), 0, st, dg, key, payload, (uint32_t*)c->d_lpos.p, (uint32_t*)c->d_rpos.p, cnt_fast, cnt_sel1, 2));
+    KT(c, st, VO_K_HARRIS, hipLaunchKernelGGL(k_harris, dim3(8, g.nlevels, F), dim3(256), 0, st, dg, src, pyr, cnt_sel1, key, payload));
     if (c->debug_stop == 2) { HIP_TRY(c, hipGetLastError()); return VO_OK; }
-    hipLaunchKernelGGL(k_select<512>, dim3(g.nlevels, F), dim3(512), 0, st, dg, key, payload, (uint32_t*)c->d_lpos.p, (uint32_t*)c->d_rpos.p, cnt_sel1, cnt_sel2, 1);
-    STAGE_MARK(c, st, VO_STAGE_ORIENT);
-    hipLaunchKernelGGL(k_orient, dim3(16, g.nlevels, F), dim3(256), 0, st, dg, src, pyr, cnt_sel2, key, payload, (vo_keypoint*)c->d_kp.p,
-                       (uint32_t*)c->d_kplvl.p, (int*)c->d_nkp.p, (int*)c->d_frame_status.p);
-    STAGE_MARK(c, st, VO_STAGE_BLUR);
+    KT(c, st, VO_K_SELECT2, hipLaunchKernelGGL(k_select<512>, dim3(g.nlevels, F), dim3(512), 0, st, dg, key, payload, (uint32_t*)c->d_lpos.p, (uint32_t*)c->d_rpos.p, cnt_sel1, cnt_sel2, 1));
+    KT(c, st, VO_K_ORIENT, hipLaunchKernelGGL(k_orient, dim3(16, g.nlevels, F), dim3(256), 0, st, dg, src, pyr, cnt_sel2, key, payload, (vo_keypoint*)c->d_kp.p,
+                       (uint32_t*)c->d_kplvl.p, (int*)c->d_nkp.p, (int*)c->d_frame_status.p));
     BlurK bk;
     gaussian_kernel7_sigma2(bk);
-    hipLaunchKernelGGL(k_blur, dim3(g.nbtiles, F), dim3(256), 0, st, dg, src, pyr, blur, (const TileDesc*)c->d_btiles.p, bk);
-    STAGE_MARK(c, st, VO_STAGE_DESCRIBE);
-    hipLaunchKernelGGL(k_rbrief, dim3((g.kp_cap + 3) / 4, F), dim3(256), 0, st, dg, blur, (const signed char*)c->d_pat.p, (const int*)c->d_nkp.p,
-                       (const vo_keypoint*)c->d_kp.p, (const uint32_t*)c->d_kplvl.p, (uint8_t*)c->d_desc.p);
-    STAGE_MARK(c, st, VO_STAGE_MATCH);
+    KT(c, st, VO_K_BLUR, hipLaunchKernelGGL(k_blur, dim3(g.nbtiles, F), dim3(256), 0, st, dg, src, pyr, blur, (const TileDesc*)c->d_btiles.p, bk));
+    KT(c, st, VO_K_RBRIEF, hipLaunchKernelGGL(k_rbrief, dim3((g.kp_cap + 3) / 4, F), dim3(256), 0, st, dg, blur, (const signed char*)c->d_pat.p, (const int*)c->d_nkp.p,
+                       (const vo_keypoint*)c->d_kp.p, (const uint32_t*)c->d_kplvl.p, (uint8_t*)c->d_desc.p));
     HIP_TRY(c, hipGetLastError());
     return VO_OK;
 }

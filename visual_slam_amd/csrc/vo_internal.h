@@ -124,10 +124,19 @@ struct vo_ctx {
     FrameSrc last_src{};
     int last_frames = 0, last_pairs = 0;
 
+    // per-kernel timing with HIP events on the launch stream (diagnostic mode)
     bool timing = false;
-    float stage_ms[VO_N_STAGES] = {0};
-    hipEvent_t ev[VO_N_STAGES + 1] = {nullptr};
+    float kernel_ms[VO_N_KERNELS] = {0};
+    int kernel_launches[VO_N_KERNELS] = {0};
+    std::vector<hipEvent_t> ev_pool;
+    std::vector<int> ev_ids;      // kernel id of each bracketed launch; events 2*i, 2*i+1
 };
+
+void kt_begin(vo_ctx* c, hipStream_t st, int id);
+void kt_end(vo_ctx* c, hipStream_t st);
+int kt_collect(vo_ctx* c);   // after the stream is synchronised
+#define KT(c, st, id, launch) \
+    do { kt_begin((c), (st), (id)); launch; kt_end((c), (st)); } while (0)
 
 int vo_fail(vo_ctx* c, int code, const std::string& msg);
 #define HIP_TRY(c, expr)                                                                         \

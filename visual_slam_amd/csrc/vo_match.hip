@@ -118,10 +118,10 @@ __global__ __launch_bounds__(1024) void k_ratio(const uint2* __restrict__ seg_be
 int vo_launch_match_impl(vo_ctx* c, int P, int nA, double ratio, int pair0, int4* raw_out, hipStream_t st) {
     const int kp_cap = c->kp_cap;
     dim3 grid((kp_cap + 255) / 256, MATCH_SPLIT, P);
-    hipLaunchKernelGGL(k_match, grid, dim3(256), 0, st, (const uint8_t*)c->d_desc.p, (const int*)c->d_nkp.p, kp_cap, nA, (uint2*)c->d_match.p);
-    hipLaunchKernelGGL(k_ratio, dim3(P), dim3(1024), 0, st, (const uint2*)c->d_match.p, (const int*)c->d_nkp.p, kp_cap, nA,
+    KT(c, st, VO_K_MATCH, hipLaunchKernelGGL(k_match, grid, dim3(256), 0, st, (const uint8_t*)c->d_desc.p, (const int*)c->d_nkp.p, kp_cap, nA, (uint2*)c->d_match.p));
+    KT(c, st, VO_K_RATIO, hipLaunchKernelGGL(k_ratio, dim3(P), dim3(1024), 0, st, (const uint2*)c->d_match.p, (const int*)c->d_nkp.p, kp_cap, nA,
                        (const vo_keypoint*)c->d_kp.p, ratio, pair0, (int4*)c->d_mq.p, (float2*)c->d_q1.p, (float2*)c->d_q2.p,
-                       (int*)c->d_nmatch.p, (int*)c->d_pair_status.p, (int2*)c->d_pair_nkp.p, (const int*)c->d_frame_status.p, raw_out);
+                       (int*)c->d_nmatch.p, (int*)c->d_pair_status.p, (int2*)c->d_pair_nkp.p, (const int*)c->d_frame_status.p, raw_out));
     HIP_TRY(c, hipGetLastError());
     return VO_OK;
 }
