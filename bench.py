@@ -58,8 +58,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--pairs", type=int, default=256, help="frame pairs per GPU per step")
+    ap.add_argument("--pairs", type=int, default=1024, help="frame pairs per GPU per step")
+    ap.add_argument("--distinct", type=int, default=256, help="distinct seeded pairs generated per GPU (tiled up to --pairs)")
     ap.add_argument("--chunk", type=int, default=32, help="pairs per detect/match launch wave")
+    ap.add_argument("--workers", type=int, default=0, help="host processes for input generation (0 = auto; use 1 under rocprofv3)")
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
 
@@ -79,8 +81,13 @@ def main():
     from visual_slam_amd import _lib, synth
 
     B = args.pairs
-    workers = max(1, min(16, (os.cpu_count() or 1) // max(world, 1)))
-    imgsA, imgsB = synth.make_batch(range(rank * B, rank * B + B), W_IMG, H_IMG, workers=workers)
+    workers = args.workers if args.workers > 0 else max(1, min(12, (os.cpu_count() or 1) // max(world, 1)))
+    nd = min(B, args.distinct)
+    imgsA, imgsB = synth.make_batch(range(rank * nd, rank * nd + nd), W_IMG, H_IMG, workers=workers)
+    if nd < B:  # tile the distinct pairs up to the batch size (same work per pair, bounded host set-up time)
+        reps = (B + nd - 1) // nd
+        imgsA = np.concatenate([imgsA] * reps)[:B]
+        imgsB = np.concatenate([imgsB] * reps)[:B]
     K = synth.K_KITTI02
     dA = torch.from_numpy(imgsA).cuda()
     dB = torch.from_numpy(imgsB).cuda()
@@ -150,7 +157,7 @@ def main():
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8/int32 detect+match, f64 pose", "data": "synthetic",
             "config": {"workload": "configs[2]: batch of synthetic 1241x376 pairs (configs[1] generator, seeds 0..), 3000 ORB features, 8 levels",
-                       "pairs_per_gpu": B, "global_pairs": world * B, "chunk_pairs": min(args.chunk, B), "parallelism": "pairs sharded over ranks, no collective",
+                       "pairs_per_gpu": B, "distinct_pairs_per_gpu": nd, "global_pairs": world * B, "chunk_pairs": min(args.chunk, B), "parallelism": "pairs sharded over ranks, no collective",
                        "pairs_ok": ok},
             "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels,
         }

@@ -36,13 +36,11 @@ static void linear_coeffs(int src, int dst, ResizeCoef* out) {
     for (int d = 0; d < dst; d++) {
         double f = scale * ((double)d + 0.5) - 0.5;
         int i = cvFloorD(f);
-        ResizeCoef c{0, 0, 0, 0};
+        // packed: source index | fraction c1 << 16 (c0 = 256 - c1); clamped ends have c1 = 0
+        ResizeCoef c = 0;
         if (i >= 0 && src > 1) {
-            if (i < src - 1) {
-                c.ofs0 = i; c.ofs1 = i + 1; c.c1 = cvRoundD((f - (double)i) * 256.0);
-            } else {
-                c.ofs0 = c.ofs1 = src - 1;
-            }
+            if (i < src - 1) c = (uint32_t)i | ((uint32_t)cvRoundD((f - (double)i) * 256.0) << 16);
+            else c = (uint32_t)(src - 1);
         }
         out[d] = c;
     }
@@ -86,8 +84,8 @@ int vo_build_geometry(vo_ctx* c, int w, int h) {
         L.cand_ofs = cand_ofs;
         cand_ofs += L.cand_cap;
         if (l > 0) {
-            L.xtab = rt; rt += L.w;
-            L.ytab = rt; rt += L.h;
+            L.xtab = rt; rt += (int)align_up(L.w, 4);   // 16-byte aligned rows of 4 coefficients
+            L.ytab = rt; rt += (int)align_up(L.h, 4);
         }
         L.bntx = (L.w + VO_BLUR_TW - 1) / VO_BLUR_TW;
         L.bnty = (L.h + VO_BLUR_TH - 1) / VO_BLUR_TH;
@@ -113,7 +111,7 @@ int vo_build_geometry(vo_ctx* c, int w, int h) {
 
     c->h_tiles.assign(std::max(g.ntiles, 1), TileDesc{0, 0, 0, 0});
     c->h_btiles.assign(std::max(g.nbtiles, 1), TileDesc{0, 0, 0, 0});
-    c->h_rtab.assign(std::max(rt, 1), ResizeCoef{0, 0, 0, 0});
+    c->h_rtab.assign(std::max(rt, 1), 0);
     for (int l = 0; l < p.nlevels; l++) {
         const LevelGeom& L = g.lv[l];
         for (int ty = 0; ty < L.nty; ty++)
@@ -143,7 +141,9 @@ int vo_build_geometry(vo_ctx* c, int w, int h) {
 
 // ------------------------------------------------------------------ pyramid
 // level l from level l-1: H = c0x*p[i] + c1x*p[i+1] (u16), out = (c0y*H0 + c1y*H1 + 32768) >> 16.
-// One thread makes 4 adjacent pixels and stores them as one dword.
+// One lane makes 4 adjacent pixels: one 16-byte coefficient load, one 8-byte load from each of
+// the two source rows (the 4 outputs read at most 7 consecutive source bytes for scale <= 2),
+// one dword store.
 __global__ __launch_bounds__(256) void k_pyramid(const Geom* __restrict__ g, FrameSrc src, uint8_t* __restrict__ pyr,
                                                  const ResizeCoef* __restrict__ rt, int l) {
     const LevelGeom& L = g->lv[l];
@@ -153,21 +153,42 @@ __global__ __launch_bounds__(256) void k_pyramid(const Geom* __restrict__ g, Fra
     if (y >= L.h || x4 >= L.w) return;
     int spitch;
     const uint8_t* sp = level_ptr(g, src, pyr, f, l - 1, spitch);
-    const ResizeCoef cy = rt[L.ytab + y];
-    const uint8_t* r0 = sp + (long)cy.ofs0 * spitch;
-    const uint8_t* r1 = sp + (long)cy.ofs1 * spitch;
-    const uint32_t c1y = cy.c1, c0y = 256 - cy.c1;
+    const int sw = g->lv[l - 1].w, sh = g->lv[l - 1].h;
+    const uint32_t cy = rt[L.ytab + y];
+    const int oy = (int)(cy & 0xFFFF);
+    const uint8_t* r0 = sp + (long)oy * spitch;
+    const uint8_t* r1 = sp + (long)min(oy + 1, sh - 1) * spitch;
+    const uint32_t c1y = cy >> 16, c0y = 256 - c1y;
+    const uint4 cx4 = *reinterpret_cast<const uint4*>(rt + L.xtab + x4);
+    const uint32_t cx[4] = {cx4.x, cx4.y, cx4.z, cx4.w};
+    const int nvalid = min(4, L.w - x4);
+    const int o0 = (int)(cx[0] & 0xFFFF);
+    const int olast = (int)(cx[nvalid - 1] & 0xFFFF);
     uint32_t packed = 0;
+    if (olast + 1 - o0 < 8 && o0 + 8 <= sw) {
+        unsigned long long a, b;
+        __builtin_memcpy(&a, r0 + o0, 8);
+        __builtin_memcpy(&b, r1 + o0, 8);
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        int x = x4 + i;
-        if (x < L.w) {
-            const ResizeCoef cx = rt[L.xtab + x];
-            uint32_t c1 = cx.c1, c0 = 256 - cx.c1;
-            uint32_t h0 = c0 * r0[cx.ofs0] + c1 * r0[cx.ofs1];
-            uint32_t h1 = c0 * r1[cx.ofs0] + c1 * r1[cx.ofs1];
-            uint32_t o = (c0y * h0 + c1y * h1 + 32768u) >> 16;
-            packed |= o << (8 * i);
+        for (int i = 0; i < 4; i++) {
+            if (i < nvalid) {
+                const int rel = (int)(cx[i] & 0xFFFF) - o0;
+                const uint32_t c1 = cx[i] >> 16, c0 = 256 - c1;
+                const uint32_t p00 = (uint32_t)(a >> (8 * rel)) & 0xFF, p01 = (uint32_t)(a >> (8 * rel + 8)) & 0xFF;
+                const uint32_t p10 = (uint32_t)(b >> (8 * rel)) & 0xFF, p11 = (uint32_t)(b >> (8 * rel + 8)) & 0xFF;
+                const uint32_t h0 = c0 * p00 + c1 * p01, h1 = c0 * p10 + c1 * p11;
+                packed |= ((c0y * h0 + c1y * h1 + 32768u) >> 16) << (8 * i);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            if (i < nvalid) {
+                const int ox = (int)(cx[i] & 0xFFFF), ox1 = min(ox + 1, sw - 1);
+                const uint32_t c1 = cx[i] >> 16, c0 = 256 - c1;
+                const uint32_t h0 = c0 * r0[ox] + c1 * r0[ox1], h1 = c0 * r1[ox] + c1 * r1[ox1];
+                packed |= ((c0y * h0 + c1y * h1 + 32768u) >> 16) << (8 * i);
+            }
         }
     }
     uint8_t* dp = pyr + (long)f * g->pyr_frame + L.pyr_ofs + (long)y * L.pitch + x4;
@@ -175,16 +196,12 @@ __global__ __launch_bounds__(256) void k_pyramid(const Geom* __restrict__ g, Fra
 }
 
 // ------------------------------------------------------------------ FAST-9/16
-__device__ __forceinline__ bool has9(uint32_t m) {
-    m |= m << 16;
-    uint32_t a = m & (m >> 1);
-    a &= a >> 2;
-    a &= a >> 4;
-    a &= m >> 8;
-    return (a & 0xFFFFu) != 0;
-}
-
+// The segment test is evaluated in min/max form, without per-pixel bit masks:
+//   darker  arc of 9 all < v-t   <=>  min over the 16 arcs of (max over the arc of p) < v - t
+//   brighter arc of 9 all > v+t  <=>  max over the 16 arcs of (min over the arc of p) > v + t
+// and cornerScore<16> = max(v - min_arcs max9(p), max_arcs min9(p) - v) - 1.
 #define PXP 48  // LDS pixel tile pitch
+#define PXO 3   // column of the LDS tile that holds image column x0-4 (the tile is loaded from a dword boundary)
 // circle offsets k = 0..15 as (dx,dy): (0,3)(1,3)(2,2)(3,1)(3,0)(3,-1)(2,-2)(1,-3)(0,-3)(-1,-3)(-2,-2)(-3,-1)(-3,0)(-3,1)(-2,2)(-1,3)
 #define CIRC(k) (((k) == 0 ? 3 : (k) == 1 ? 3 : (k) == 2 ? 2 : (k) == 3 ? 1 : (k) == 4 ? 0 : (k) == 5 ? -1 : (k) == 6 ? -2 : (k) == 7 ? -3 : \
                   (k) == 8 ? -3 : (k) == 9 ? -3 : (k) == 10 ? -2 : (k) == 11 ? -1 : (k) == 12 ? 0 : (k) == 13 ? 1 : (k) == 14 ? 2 : 3) * PXP + \
@@ -194,58 +211,92 @@ __device__ __forceinline__ bool has9(uint32_t m) {
 // 0 for a non-corner, else cornerScore<16> (largest threshold that keeps it a corner, minus 1)
 __device__ __forceinline__ int fast_score_lds(const uint8_t* p, int thr) {
     const int v = p[0];
-    int d[16];
-    uint32_t md = 0, mb = 0;
+    int x[16];
 #pragma unroll
-    for (int k = 0; k < 16; k++) {
-        d[k] = v - (int)p[CIRC(k)];
-        md |= (uint32_t)(d[k] > thr) << k;
-        mb |= (uint32_t)(d[k] < -thr) << k;
-    }
-    if (!(has9(md) || has9(mb))) return 0;
-    // max over the 16 arcs of 9 of min(d) and of min(-d), by doubling
+    for (int k = 0; k < 16; k++) x[k] = p[CIRC(k)];
     int lo2[16], hi2[16];
 #pragma unroll
-    for (int k = 0; k < 16; k++) { lo2[k] = min(d[k], d[(k + 1) & 15]); hi2[k] = max(d[k], d[(k + 1) & 15]); }
+    for (int k = 0; k < 16; k++) { lo2[k] = min(x[k], x[(k + 1) & 15]); hi2[k] = max(x[k], x[(k + 1) & 15]); }
     int lo4[16], hi4[16];
 #pragma unroll
     for (int k = 0; k < 16; k++) { lo4[k] = min(lo2[k], lo2[(k + 2) & 15]); hi4[k] = max(hi2[k], hi2[(k + 2) & 15]); }
-    int A = -1000, B = 1000;
+    int maxmin = 0, minmax = 255;
 #pragma unroll
     for (int k = 0; k < 16; k++) {
-        int lo9 = min(min(lo4[k], lo4[(k + 4) & 15]), d[(k + 8) & 15]);
-        int hi9 = max(max(hi4[k], hi4[(k + 4) & 15]), d[(k + 8) & 15]);
-        A = max(A, lo9);
-        B = min(B, hi9);
+        const int lo9 = min(min(lo4[k], lo4[(k + 4) & 15]), x[(k + 8) & 15]);
+        const int hi9 = max(max(hi4[k], hi4[(k + 4) & 15]), x[(k + 8) & 15]);
+        maxmin = max(maxmin, lo9);
+        minmax = min(minmax, hi9);
     }
-    return max(A, -B) - 1;
+    const int best = max(v - minmax, maxmin - v);  // largest t' with all of some arc differing by >= t'
+    return best > thr ? best - 1 : 0;
 }
 
 __global__ __launch_bounds__(256) void k_fast_tiles(const Geom* __restrict__ g, FrameSrc src, const uint8_t* __restrict__ pyr,
                                                     const TileDesc* __restrict__ tiles, uint32_t* __restrict__ tile_list,
                                                     uint8_t* __restrict__ seg_cnt) {
-    __shared__ uint8_t px[40 * PXP];
+    __shared__ __attribute__((aligned(16))) uint8_t px[40 * PXP];
     __shared__ uint8_t sc[34 * 36];
-    __shared__ int wtot[4];
+    __shared__ uint16_t queue[34 * 34];
+    __shared__ int wtot[4], qn;
     const int t = blockIdx.x, f = blockIdx.y, tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
     const TileDesc td = tiles[t];
     const LevelGeom& L = g->lv[td.level];
     int pitch;
     const uint8_t* img = level_ptr(g, src, pyr, f, td.level, pitch);
     const int x0 = VO_EDGE + td.tx * VO_TILE, y0 = VO_EDGE + td.ty * VO_TILE;
-    for (int i = tid; i < 40 * 40; i += 256) {
-        int r = i / 40, c = i - r * 40;
-        int y = min(y0 - 4 + r, L.h - 1), x = min(x0 - 4 + c, L.w - 1);
-        px[r * PXP + c] = img[(long)y * pitch + x];
+    // 40 rows x 44 bytes from the dword boundary xa = x0-4-PXO (a multiple of 4), as 11 dwords per row
+    const int xa = x0 - 4 - PXO;
+    if (tid == 0) qn = 0;
+    for (int i = tid; i < 40 * 11; i += 256) {
+        const int r = i / 11, k = i - r * 11;
+        const int y = min(y0 - 4 + r, L.h - 1), x = xa + 4 * k;
+        const uint8_t* rp = img + (long)y * pitch;
+        uint32_t v;
+        if (x + 3 < L.w) {
+            __builtin_memcpy(&v, rp + x, 4);  // level 0 rows may be unaligned (caller's stride)
+        } else {
+            v = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) v |= (uint32_t)rp[min(x + j, L.w - 1)] << (8 * j);
+        }
+        *reinterpret_cast<uint32_t*>(&px[r * PXP + 4 * k]) = v;
     }
     __syncthreads();
     const int thr = g->fast_threshold;
-    for (int i = tid; i < 34 * 34; i += 256) {
-        int r = i / 34, c = i - r * 34;
-        int xi = x0 - 1 + c, yi = y0 - 1 + r;
-        int s = 0;
-        if (xi < L.w - 3 && yi < L.h - 3) s = fast_score_lds(&px[(r + 3) * PXP + c + 3], thr);
-        sc[r * 36 + c] = (uint8_t)s;
+    // Stage 1 (every position): a 9-arc contains one pixel of every opposite pair, so with the
+    // four even pairs  min_k max(p_k, p_k+8) > v+t  or  max_k min(p_k, p_k+8) < v-t  is necessary.
+    // Survivors are queued so that stage 2 (all 16 arcs + score) runs on dense wavefronts.
+    for (int i0 = 0; i0 < 34 * 34; i0 += 256) {
+        const int i = i0 + tid;
+        bool pass = false;
+        if (i < 34 * 34) {
+            const int r = i / 34, c = i - r * 34;
+            const int xi = x0 - 1 + c, yi = y0 - 1 + r;
+            sc[r * 36 + c] = 0;
+            if (xi < L.w - 3 && yi < L.h - 3) {
+                const uint8_t* p = &px[(r + 3) * PXP + c + 3 + PXO];
+                const int v = p[0];
+                const int a0 = p[CIRC(0)], a8 = p[CIRC(8)], a2 = p[CIRC(2)], a10 = p[CIRC(10)];
+                const int a4 = p[CIRC(4)], a12 = p[CIRC(12)], a6 = p[CIRC(6)], a14 = p[CIRC(14)];
+                const int mm = min(min(max(a0, a8), max(a2, a10)), min(max(a4, a12), max(a6, a14)));
+                const int xm = max(max(min(a0, a8), min(a2, a10)), max(min(a4, a12), min(a6, a14)));
+                pass = (mm > v + thr) || (xm < v - thr);
+            }
+        }
+        const unsigned long long m = __ballot(pass);
+        int base = 0;
+        if (lane == 0 && m) base = atomicAdd(&qn, (int)__popcll(m));
+        base = __shfl(base, 0);
+        if (pass) queue[base + (int)__popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)i;
+    }
+    __syncthreads();
+    const int nq = qn;
+    for (int q = tid; q < nq; q += 256) {
+        const int i = queue[q];
+        const int r = i / 34, c = i - r * 34;
+        sc[r * 36 + c] = (uint8_t)fast_score_lds(&px[(r + 3) * PXP + c + 3 + PXO], thr);
     }
     __syncthreads();
     // 3x3 non-max suppression (strict) + border filter; thread = 4 adjacent pixels of one row
@@ -264,7 +315,6 @@ __global__ __launch_bounds__(256) void k_fast_tiles(const Geom* __restrict__ g, 
             if (keep && cnt < 2) ent[cnt++] = PACK_XYS(xi, yi, s);
         }
     }
-    const int lane = tid & 63, wave = tid >> 6;
     int incl = cnt;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -617,7 +667,8 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x, bool use_fma) 
 
 __constant__ int c_umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
 
-// 32 lanes per keypoint: lane = column u+15, loop over the 31 rows of the disc.
+// One wavefront per keypoint: lane = (row group, 4-byte column group); the 31 x 32-byte window
+// of the disc is read as 4 unaligned dwords per lane, integer moments reduced across the wave.
 __global__ __launch_bounds__(256) void k_orient(const Geom* __restrict__ g, FrameSrc src, const uint8_t* __restrict__ pyr,
                                                 const int* __restrict__ cnt_sel2, const float* __restrict__ key,
                                                 const uint32_t* __restrict__ payload, vo_keypoint* __restrict__ kps,
@@ -638,30 +689,43 @@ __global__ __launch_bounds__(256) void k_orient(const Geom* __restrict__ g, Fram
     int pitch;
     const uint8_t* img = level_ptr(g, src, pyr, f, l, pitch);
     const long cb = (long)f * g->cand_frame + L.cand_ofs;
-    const int sub = threadIdx.x >> 5, u = (threadIdx.x & 31) - 15;
-    for (int i = blockIdx.x * 8 + sub; i < n; i += gridDim.x * 8) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int rg = lane >> 3, u0 = -16 + 4 * (lane & 7);
+    // per-lane row offsets and disc limits of its (up to) 4 rows
+    int vrow[4], um[4];
+#pragma unroll
+    for (int it = 0; it < 4; it++) {
+        const int v = -15 + rg + 8 * it;
+        vrow[it] = v;
+        um[it] = v <= 15 ? c_umax[v < 0 ? -v : v] : -1;
+    }
+    for (int i = blockIdx.x * 4 + wave; i < n; i += gridDim.x * 4) {
         const uint32_t p = payload[cb + i];
         const int x0 = UNPACK_X(p), y0 = UNPACK_Y(p);
         const uint8_t* center = img + (long)y0 * pitch + x0;
         int m10 = 0, m01 = 0;
-        if (u <= 15) {
-            const int au = u < 0 ? -u : u;
 #pragma unroll
-            for (int v = -15; v <= 15; v++) {
-                const int av = v < 0 ? -v : v;
-                if (au <= c_umax[av]) {
-                    int val = center[(long)v * pitch + u];
+        for (int it = 0; it < 4; it++) {
+            if (um[it] >= 0) {
+                uint32_t d;
+                __builtin_memcpy(&d, center + (long)vrow[it] * pitch + u0, 4);
+                int rs = 0;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int u = u0 + j;
+                    const int val = ((u < 0 ? -u : u) <= um[it]) ? (int)((d >> (8 * j)) & 0xFF) : 0;
                     m10 += u * val;
-                    m01 += v * val;
+                    rs += val;
                 }
+                m01 += vrow[it] * rs;
             }
         }
 #pragma unroll
-        for (int o = 16; o > 0; o >>= 1) {
+        for (int o = 32; o > 0; o >>= 1) {
             m10 += __shfl_xor(m10, o);
             m01 += __shfl_xor(m01, o);
         }
-        if ((threadIdx.x & 31) == 0 && off + i < g->kp_cap) {
+        if (lane == 0 && off + i < g->kp_cap) {
             vo_keypoint k;
             k.x = (float)x0 * L.scale;
             k.y = (float)y0 * L.scale;
@@ -684,88 +748,133 @@ __device__ __forceinline__ int reflect101c(int i, int n) {
 }
 
 struct BlurK { float k[4]; };  // k[0] = centre weight, k[i] = weight at distance i
+__device__ __forceinline__ float comp4(const float4& v, int j) { return j == 0 ? v.x : j == 1 ? v.y : j == 2 ? v.z : v.w; }
+__device__ __forceinline__ int comp4(const int4& v, int j) { return j == 0 ? v.x : j == 1 ? v.y : j == 2 ? v.z : v.w; }
 
+#define BL_SP 80                      // LDS source tile pitch (bytes): 72 used
+#define BL_ROWS (VO_BLUR_TH + 6)
+
+// Tile = 64 x VO_BLUR_TH outputs.  Source window = (TH+6) rows x 72 bytes from the dword boundary
+// x0-4.  Row pass: one lane makes 4 adjacent outputs from 3 LDS dwords (10 bytes -> float by
+// v_cvt_f32_ubyteN) and stores a float4; column pass: one lane makes 4 adjacent outputs from 7
+// float4 rows and stores one dword.  The multiply/add order is sepFilter2D's (see oracle).
 __global__ __launch_bounds__(256) void k_blur(const Geom* __restrict__ g, FrameSrc src, const uint8_t* __restrict__ pyr,
                                               uint8_t* __restrict__ blur, const TileDesc* __restrict__ btiles, BlurK bk) {
-    __shared__ uint8_t sp[(VO_BLUR_TH + 6) * 72];
-    __shared__ float rowf[(VO_BLUR_TH + 6) * VO_BLUR_TW];
+    __shared__ __attribute__((aligned(16))) uint8_t sp[BL_ROWS * BL_SP];
+    __shared__ __attribute__((aligned(16))) float rowf[BL_ROWS * VO_BLUR_TW];
     const int f = blockIdx.y, tid = threadIdx.x;
     const TileDesc td = btiles[blockIdx.x];
     const LevelGeom& L = g->lv[td.level];
     int pitch;
     const uint8_t* img = level_ptr(g, src, pyr, f, td.level, pitch);
     const int x0 = td.tx * VO_BLUR_TW, y0 = td.ty * VO_BLUR_TH;
-    for (int i = tid; i < (VO_BLUR_TH + 6) * 70; i += 256) {
-        int r = i / 70, c = i - r * 70;
-        int y = reflect101c(y0 - 3 + r, L.h), x = reflect101c(x0 - 3 + c, L.w);
-        sp[r * 72 + c] = img[(long)y * pitch + x];
+    for (int i = tid; i < BL_ROWS * 18; i += 256) {
+        const int r = i / 18, k = i - r * 18;
+        const int y = reflect101c(y0 - 3 + r, L.h), x = x0 - 4 + 4 * k;
+        const uint8_t* rp = img + (long)y * pitch;
+        uint32_t v;
+        if (x >= 0 && x + 3 < L.w) {
+            __builtin_memcpy(&v, rp + x, 4);
+        } else {
+            v = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) v |= (uint32_t)rp[reflect101c(x + j, L.w)] << (8 * j);
+        }
+        *reinterpret_cast<uint32_t*>(&sp[r * BL_SP + 4 * k]) = v;
     }
     __syncthreads();
     const bool use_fma = g->fma != 0;
     const int mode = g->blur_mode;
     int* rowi = reinterpret_cast<int*>(rowf);
-    for (int i = tid; i < (VO_BLUR_TH + 6) * VO_BLUR_TW; i += 256) {
-        int r = i / VO_BLUR_TW, c = i - r * VO_BLUR_TW;
-        const uint8_t* q = &sp[r * 72 + c];
+    for (int i = tid; i < BL_ROWS * 16; i += 256) {
+        const int r = i >> 4, c4 = (i & 15) * 4;
+        const uint32_t* q = reinterpret_cast<const uint32_t*>(&sp[r * BL_SP + c4]);
+        const uint32_t d0 = q[0], d1 = q[1], d2 = q[2];
+        // bytes c4+1 .. c4+10 of the window: b[j] = source pixel at output x0+c4+j-3
+        uint32_t b[10];
+        b[0] = (d0 >> 8) & 0xFF; b[1] = (d0 >> 16) & 0xFF; b[2] = d0 >> 24;
+        b[3] = d1 & 0xFF; b[4] = (d1 >> 8) & 0xFF; b[5] = (d1 >> 16) & 0xFF; b[6] = d1 >> 24;
+        b[7] = d2 & 0xFF; b[8] = (d2 >> 8) & 0xFF; b[9] = (d2 >> 16) & 0xFF;
         if (mode == 1) {
-            rowi[i] = 18 * (q[0] + q[6]) + 34 * (q[1] + q[5]) + 49 * (q[2] + q[4]) + 55 * q[3];
+            int op[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                op[j] = 18 * (int)(b[j] + b[j + 6]) + 34 * (int)(b[j + 1] + b[j + 5]) + 49 * (int)(b[j + 2] + b[j + 4]) + 55 * (int)b[j + 3];
+            *reinterpret_cast<int4*>(&rowi[r * VO_BLUR_TW + c4]) = make_int4(op[0], op[1], op[2], op[3]);
         } else {
-            // RowFilter<uchar,float>: s = k[0]*p[-3]; s += k[j]*p[j-3] left to right
-            float acc = bk.k[3] * (float)q[0];
-            if (use_fma) {
-                acc = __fmaf_rn(bk.k[2], (float)q[1], acc);
-                acc = __fmaf_rn(bk.k[1], (float)q[2], acc);
-                acc = __fmaf_rn(bk.k[0], (float)q[3], acc);
-                acc = __fmaf_rn(bk.k[1], (float)q[4], acc);
-                acc = __fmaf_rn(bk.k[2], (float)q[5], acc);
-                acc = __fmaf_rn(bk.k[3], (float)q[6], acc);
-            } else {
-                acc = acc + bk.k[2] * (float)q[1];
-                acc = acc + bk.k[1] * (float)q[2];
-                acc = acc + bk.k[0] * (float)q[3];
-                acc = acc + bk.k[1] * (float)q[4];
-                acc = acc + bk.k[2] * (float)q[5];
-                acc = acc + bk.k[3] * (float)q[6];
+            float fb[10];
+#pragma unroll
+            for (int j = 0; j < 10; j++) fb[j] = (float)b[j];
+            float op[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                // RowFilter<uchar,float>: s = k[0]*p[-3]; s += k[i]*p[i-3] left to right
+                float acc = bk.k[3] * fb[j];
+                if (use_fma) {
+                    acc = __fmaf_rn(bk.k[2], fb[j + 1], acc);
+                    acc = __fmaf_rn(bk.k[1], fb[j + 2], acc);
+                    acc = __fmaf_rn(bk.k[0], fb[j + 3], acc);
+                    acc = __fmaf_rn(bk.k[1], fb[j + 4], acc);
+                    acc = __fmaf_rn(bk.k[2], fb[j + 5], acc);
+                    acc = __fmaf_rn(bk.k[3], fb[j + 6], acc);
+                } else {
+                    acc = acc + bk.k[2] * fb[j + 1];
+                    acc = acc + bk.k[1] * fb[j + 2];
+                    acc = acc + bk.k[0] * fb[j + 3];
+                    acc = acc + bk.k[1] * fb[j + 4];
+                    acc = acc + bk.k[2] * fb[j + 5];
+                    acc = acc + bk.k[3] * fb[j + 6];
+                }
+                op[j] = acc;
             }
-            rowf[i] = acc;
+            *reinterpret_cast<float4*>(&rowf[r * VO_BLUR_TW + c4]) = make_float4(op[0], op[1], op[2], op[3]);
         }
     }
     __syncthreads();
-    const int r = tid >> 4, c4 = (tid & 15) * 4;
-    const int y = y0 + r;
-    if (y >= L.h || x0 + c4 >= L.w) return;
-    uint32_t packed = 0;
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const int c = c4 + j;
-        int o;
+    for (int i = tid; i < VO_BLUR_TH * 16; i += 256) {
+        const int r = i >> 4, c4 = (i & 15) * 4;
+        const int y = y0 + r;
+        if (y >= L.h || x0 + c4 >= L.w) continue;
+        uint32_t packed = 0;
         if (mode == 1) {
-            const int* q = &rowi[(r + 3) * VO_BLUR_TW + c];
-            int s = 18 * (q[-3 * VO_BLUR_TW] + q[3 * VO_BLUR_TW]) + 34 * (q[-2 * VO_BLUR_TW] + q[2 * VO_BLUR_TW]) +
-                    49 * (q[-VO_BLUR_TW] + q[VO_BLUR_TW]) + 55 * q[0];
-            o = min(max((s + 32768) >> 16, 0), 255);
-        } else {
-            // SymmColumnFilter: s = k0*row[0] + delta; s += k[i]*(row[i] + row[-i])
-            const float* q = &rowf[(r + 3) * VO_BLUR_TW + c];
-            float acc = bk.k[0] * q[0] + 0.f;
-            const float t1 = q[VO_BLUR_TW] + q[-VO_BLUR_TW];
-            const float t2 = q[2 * VO_BLUR_TW] + q[-2 * VO_BLUR_TW];
-            const float t3 = q[3 * VO_BLUR_TW] + q[-3 * VO_BLUR_TW];
-            if (use_fma) {
-                acc = __fmaf_rn(bk.k[1], t1, acc);
-                acc = __fmaf_rn(bk.k[2], t2, acc);
-                acc = __fmaf_rn(bk.k[3], t3, acc);
-            } else {
-                acc = acc + bk.k[1] * t1;
-                acc = acc + bk.k[2] * t2;
-                acc = acc + bk.k[3] * t3;
+            int4 q[7];
+#pragma unroll
+            for (int k = 0; k < 7; k++) q[k] = *reinterpret_cast<const int4*>(&rowi[(r + k) * VO_BLUR_TW + c4]);
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int s = 18 * (comp4(q[0], j) + comp4(q[6], j)) + 34 * (comp4(q[1], j) + comp4(q[5], j)) +
+                              49 * (comp4(q[2], j) + comp4(q[4], j)) + 55 * comp4(q[3], j);
+                // s >= 0 here, so an unsigned shift + umin is the saturate_cast.  (Written this way on purpose:
+                // hipcc 7.2 folds `clamp(x >> 16, 0, 255)` pairs into v_ashr_pk_u8_i32 and then ORs byte 2
+                // over its upper half, which the instruction does not leave zero on gfx950 -- wrong pixels.)
+                packed |= min((uint32_t)(s + 32768) >> 16, 255u) << (8 * j);
             }
-            o = min(max(__float2int_rn(acc), 0), 255);
+        } else {
+            float4 q[7];
+#pragma unroll
+            for (int k = 0; k < 7; k++) q[k] = *reinterpret_cast<const float4*>(&rowf[(r + k) * VO_BLUR_TW + c4]);
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                // SymmColumnFilter: s = k0*row[0] + delta; s += k[i]*(row[i] + row[-i])
+                float acc = bk.k[0] * comp4(q[3], j) + 0.f;
+                const float t1 = comp4(q[4], j) + comp4(q[2], j);
+                const float t2 = comp4(q[5], j) + comp4(q[1], j);
+                const float t3 = comp4(q[6], j) + comp4(q[0], j);
+                if (use_fma) {
+                    acc = __fmaf_rn(bk.k[1], t1, acc);
+                    acc = __fmaf_rn(bk.k[2], t2, acc);
+                    acc = __fmaf_rn(bk.k[3], t3, acc);
+                } else {
+                    acc = acc + bk.k[1] * t1;
+                    acc = acc + bk.k[2] * t2;
+                    acc = acc + bk.k[3] * t3;
+                }
+                packed |= (uint32_t)min(max(__float2int_rn(acc), 0), 255) << (8 * j);
+            }
         }
-        packed |= (uint32_t)o << (8 * j);
+        uint8_t* dp = blur + (long)f * g->blur_frame + L.blur_ofs + (long)y * L.bpitch + x0 + c4;
+        *reinterpret_cast<uint32_t*>(dp) = packed;
     }
-    uint8_t* dp = blur + (long)f * g->blur_frame + L.blur_ofs + (long)y * L.bpitch + x0 + c4;
-    *reinterpret_cast<uint32_t*>(dp) = packed;
 }
 
 // ------------------------------------------------------------------ rBRIEF-256, one wavefront per keypoint

@@ -12,7 +12,7 @@
 #define VO_TILE 32          // FAST tile edge (output pixels)
 #define VO_TILE_CAP 256     // a 32x32 tile holds at most 256 strict 3x3 maxima
 #define VO_BLUR_TW 64
-#define VO_BLUR_TH 16
+#define VO_BLUR_TH 32
 
 struct LevelGeom {
     int w, h, pitch;        // level size; row pitch of the level inside the pyramid slab
@@ -47,7 +47,7 @@ struct Geom {
 struct TileDesc { short level, tx, ty, pad; };
 
 // resize coefficient: source offset and the 8-bit fraction c1 (c0 = 256 - c1)
-struct ResizeCoef { int ofs0, ofs1; int c1; int pad; };
+typedef uint32_t ResizeCoef;   // source index | 8-bit fraction c1 << 16
 
 // where a chunk's frames come from: frames [0,nA) are a + i*frame_stride, [nA, ...) are b + ...
 struct FrameSrc {

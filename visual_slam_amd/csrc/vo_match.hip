@@ -15,42 +15,65 @@
 // in ascending query order.  Integer ALU bound: 19 lane-ops per distance.
 #include "vo_internal.h"
 
-#define MATCH_SPLIT 4
+#define MATCH_SPLIT 8
+#define MATCH_QPB 512   // queries per 256-thread block: two per lane, so every scalar train load feeds 2x19 VALU ops
+
+__device__ __forceinline__ void match_update(const uint32_t (&a)[8], const uint32_t* __restrict__ b, uint32_t j, uint32_t& k1, uint32_t& k2) {
+    uint32_t d = __popc(a[0] ^ b[0]);
+    d += __popc(a[1] ^ b[1]);
+    d += __popc(a[2] ^ b[2]);
+    d += __popc(a[3] ^ b[3]);
+    d += __popc(a[4] ^ b[4]);
+    d += __popc(a[5] ^ b[5]);
+    d += __popc(a[6] ^ b[6]);
+    d += __popc(a[7] ^ b[7]);
+    const uint32_t key = (d << 16) + j;
+    const uint32_t lo = min(key, k1), hi = max(key, k1);
+    k2 = min(k2, hi);
+    k1 = lo;
+}
 
 __global__ __launch_bounds__(256) void k_match(const uint8_t* __restrict__ desc, const int* __restrict__ nkp, int kp_cap, int nA,
                                                uint2* __restrict__ seg_best) {
     const int p = blockIdx.z, seg = blockIdx.y;
     const int qf = p, tf = nA + p;
     const int nq = nkp[qf], nt = nkp[tf];
-    const int q = blockIdx.x * 256 + threadIdx.x;
-    if (blockIdx.x * 256 >= nq) return;
-    const uint32_t* qp = reinterpret_cast<const uint32_t*>(desc + ((long)qf * kp_cap + min(q, nq - 1)) * 32);
-    uint32_t a[8];
+    if (blockIdx.x * MATCH_QPB >= nq) return;
+    const int qa = blockIdx.x * MATCH_QPB + threadIdx.x, qb = qa + 256;
+    uint32_t a[8], c[8];
     {
+        const uint32_t* qp = reinterpret_cast<const uint32_t*>(desc + ((long)qf * kp_cap + min(qa, nq - 1)) * 32);
         uint4 lo = *reinterpret_cast<const uint4*>(qp), hi = *reinterpret_cast<const uint4*>(qp + 4);
         a[0] = lo.x; a[1] = lo.y; a[2] = lo.z; a[3] = lo.w; a[4] = hi.x; a[5] = hi.y; a[6] = hi.z; a[7] = hi.w;
+        qp = reinterpret_cast<const uint32_t*>(desc + ((long)qf * kp_cap + min(qb, nq - 1)) * 32);
+        lo = *reinterpret_cast<const uint4*>(qp); hi = *reinterpret_cast<const uint4*>(qp + 4);
+        c[0] = lo.x; c[1] = lo.y; c[2] = lo.z; c[3] = lo.w; c[4] = hi.x; c[5] = hi.y; c[6] = hi.z; c[7] = hi.w;
     }
     const int per = (nt + MATCH_SPLIT - 1) / MATCH_SPLIT;
     const int t0 = seg * per, t1 = min(t0 + per, nt);
     const uint32_t* tp = reinterpret_cast<const uint32_t*>(desc + (long)tf * kp_cap * 32);
-    uint32_t k1 = 0xFFFFFFFFu, k2 = 0xFFFFFFFFu;
-#pragma unroll 4
-    for (int j = t0; j < t1; j++) {
+    uint32_t ka1 = 0xFFFFFFFFu, ka2 = 0xFFFFFFFFu, kc1 = 0xFFFFFFFFu, kc2 = 0xFFFFFFFFu;
+    int j = t0;
+    for (; j + 4 <= t1; j += 4) {
+        // four wave-uniform train descriptors (scalar loads) in flight per iteration
         const uint32_t* b = tp + (long)j * 8;
-        uint32_t d = __popc(a[0] ^ b[0]);
-        d += __popc(a[1] ^ b[1]);
-        d += __popc(a[2] ^ b[2]);
-        d += __popc(a[3] ^ b[3]);
-        d += __popc(a[4] ^ b[4]);
-        d += __popc(a[5] ^ b[5]);
-        d += __popc(a[6] ^ b[6]);
-        d += __popc(a[7] ^ b[7]);
-        const uint32_t key = (d << 16) + (uint32_t)j;
-        const uint32_t lo = min(key, k1), hi = max(key, k1);
-        k2 = min(k2, hi);
-        k1 = lo;
+        uint32_t t[32];
+#pragma unroll
+        for (int k = 0; k < 32; k++) t[k] = b[k];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            match_update(a, t + 8 * u, (uint32_t)(j + u), ka1, ka2);
+            match_update(c, t + 8 * u, (uint32_t)(j + u), kc1, kc2);
+        }
     }
-    if (q < nq) seg_best[((long)p * MATCH_SPLIT + seg) * kp_cap + q] = make_uint2(k1, k2);
+    for (; j < t1; j++) {
+        const uint32_t* b = tp + (long)j * 8;
+        match_update(a, b, (uint32_t)j, ka1, ka2);
+        match_update(c, b, (uint32_t)j, kc1, kc2);
+    }
+    uint2* out = seg_best + ((long)p * MATCH_SPLIT + seg) * kp_cap;
+    if (qa < nq) out[qa] = make_uint2(ka1, ka2);
+    if (qb < nq) out[qb] = make_uint2(kc1, kc2);
 }
 
 // merge segments, ratio test, ordered compaction.  One workgroup per pair.
@@ -117,7 +140,7 @@ __global__ __launch_bounds__(1024) void k_ratio(const uint2* __restrict__ seg_be
 // pairs of the chunk: query frame p, train frame nA + p (descriptors of the last detect)
 int vo_launch_match_impl(vo_ctx* c, int P, int nA, double ratio, int pair0, int4* raw_out, hipStream_t st) {
     const int kp_cap = c->kp_cap;
-    dim3 grid((kp_cap + 255) / 256, MATCH_SPLIT, P);
+    dim3 grid((kp_cap + MATCH_QPB - 1) / MATCH_QPB, MATCH_SPLIT, P);
     KT(c, st, VO_K_MATCH, hipLaunchKernelGGL(k_match, grid, dim3(256), 0, st, (const uint8_t*)c->d_desc.p, (const int*)c->d_nkp.p, kp_cap, nA, (uint2*)c->d_match.p));
     KT(c, st, VO_K_RATIO, hipLaunchKernelGGL(k_ratio, dim3(P), dim3(1024), 0, st, (const uint2*)c->d_match.p, (const int*)c->d_nkp.p, kp_cap, nA,
                        (const vo_keypoint*)c->d_kp.p, ratio, pair0, (int4*)c->d_mq.p, (float2*)c->d_q1.p, (float2*)c->d_q2.p,

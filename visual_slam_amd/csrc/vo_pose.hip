@@ -168,32 +168,66 @@ __device__ __forceinline__ Cx cdiv(Cx a, Cx b) {
     return Cx{(a.re * b.re + a.im * b.im) * t, (-a.re * b.im + a.im * b.re) * t};
 }
 
-#define DK_T 64  // threads per solver workgroup; LDS arrays are [index][thread]
+#define DK_T 64  // threads per solver workgroup
 
-// cv::solvePoly(coeffs, roots, 300): Durand-Kerner, in-place updates, start (1+i)^k.
-// coef/rre/rim point at this thread's column of the LDS arrays (stride DK_T).
-__device__ void solve_poly10(const double* coeffs_in, double* coef, double* rre, double* rim) {
-    int n = 10;
-    for (int i = 0; i <= 10; i++) coef[i * DK_T] = coeffs_in[i];
-    for (; n > 1; n--)
-        if (fabs(coef[n * DK_T]) > DBL_EPSILON) break;
+// cv::solvePoly(coeffs, roots, 300): Durand-Kerner, in-place (Gauss-Seidel) updates, start
+// (1+i)^k.  Degree-10 fast path: roots and coefficients live in registers (every index is a
+// compile-time constant after unrolling), so a sweep is two independent fp64 chains per root
+// (Horner numerator, product denominator) with no memory traffic.  The arithmetic and its
+// order are exactly those of the generic loop below.
+__device__ __forceinline__ void dk_update_root(const double (&coef)[11], double (&rre)[10], double (&rim)[10], const int i, double& maxDiff) {
+    const Cx p{rre[i], rim[i]};
+    Cx num{coef[10], 0}, denom{coef[10], 0};
+    int num_same_root = 1;
+#pragma unroll
+    for (int j = 0; j < 10; j++) {
+        num = cadd(cmul(num, p), Cx{coef[9 - j], 0});
+        if (j != i) {
+            const Cx d = csub(p, Cx{rre[j], rim[j]});
+            if (d.re != 0 || d.im != 0) denom = cmul(denom, d);
+            else num_same_root++;
+        }
+    }
+    num = cdiv(num, denom);
+    if (num_same_root > 1 && (num_same_root % 2) == 0) {
+        const double old_re = num.re, old_im = num.im;
+        const int times = num_same_root / 2;
+        for (int j = 0; j < times; j++) {
+            num.re = old_re * old_re + old_im * old_im;
+            num.re = sqrt(num.re);
+            num.re += old_re;
+            num.im = num.re - old_re;
+            num.re /= 2;
+            num.re = sqrt(num.re);
+            num.im /= 2;
+            num.im = sqrt(num.im);
+            if (old_re < 0) num.im = -num.im;
+        }
+    }
+    rre[i] = p.re - num.re;
+    rim[i] = p.im - num.im;
+    maxDiff = fmax(maxDiff, sqrt(num.re * num.re + num.im * num.im));
+}
+
+// generic degree (leading coefficients ~ 0): same algorithm on local arrays
+__device__ __noinline__ void solve_poly_generic(const double* coeffs_in, int n, double* rre, double* rim) {
     Cx p{1, 0};
     const Cx r{1, 1};
     for (int i = 0; i < n; i++) {
-        rre[i * DK_T] = p.re; rim[i * DK_T] = p.im;
+        rre[i] = p.re; rim[i] = p.im;
         p = cmul(p, r);
     }
-    const double lead = coef[n * DK_T];
+    const double lead = coeffs_in[n];
     for (int iter = 0; iter < 300; iter++) {
         double maxDiff = 0;
         for (int i = 0; i < n; i++) {
-            p = Cx{rre[i * DK_T], rim[i * DK_T]};
+            p = Cx{rre[i], rim[i]};
             Cx num{lead, 0}, denom{lead, 0};
             int num_same_root = 1;
             for (int j = 0; j < n; j++) {
-                num = cadd(cmul(num, p), Cx{coef[(n - j - 1) * DK_T], 0});
+                num = cadd(cmul(num, p), Cx{coeffs_in[n - j - 1], 0});
                 if (j != i) {
-                    Cx d = csub(p, Cx{rre[j * DK_T], rim[j * DK_T]});
+                    Cx d = csub(p, Cx{rre[j], rim[j]});
                     if (d.re != 0 || d.im != 0) denom = cmul(denom, d);
                     else num_same_root++;
                 }
@@ -214,20 +248,58 @@ __device__ void solve_poly10(const double* coeffs_in, double* coef, double* rre,
                     if (old_re < 0) num.im = -num.im;
                 }
             }
-            rre[i * DK_T] = p.re - num.re;
-            rim[i * DK_T] = p.im - num.im;
+            rre[i] = p.re - num.re;
+            rim[i] = p.im - num.im;
             maxDiff = fmax(maxDiff, sqrt(num.re * num.re + num.im * num.im));
         }
         if (maxDiff <= 0) break;
     }
+}
+
+__device__ void solve_poly10(const double* coeffs_in, double* out_re, double* out_im) {
+    int n = 10;
+    for (; n > 1; n--)
+        if (fabs(coeffs_in[n]) > DBL_EPSILON) break;
+    if (n == 10) {
+        double coef[11], rre[10], rim[10];
+#pragma unroll
+        for (int i = 0; i <= 10; i++) coef[i] = coeffs_in[i];
+        {
+            Cx p{1, 0};
+            const Cx r{1, 1};
+#pragma unroll
+            for (int i = 0; i < 10; i++) {
+                rre[i] = p.re; rim[i] = p.im;
+                p = cmul(p, r);
+            }
+        }
+        for (int iter = 0; iter < 300; iter++) {
+            double maxDiff = 0;
+            dk_update_root(coef, rre, rim, 0, maxDiff);
+            dk_update_root(coef, rre, rim, 1, maxDiff);
+            dk_update_root(coef, rre, rim, 2, maxDiff);
+            dk_update_root(coef, rre, rim, 3, maxDiff);
+            dk_update_root(coef, rre, rim, 4, maxDiff);
+            dk_update_root(coef, rre, rim, 5, maxDiff);
+            dk_update_root(coef, rre, rim, 6, maxDiff);
+            dk_update_root(coef, rre, rim, 7, maxDiff);
+            dk_update_root(coef, rre, rim, 8, maxDiff);
+            dk_update_root(coef, rre, rim, 9, maxDiff);
+            if (maxDiff <= 0) break;
+        }
+#pragma unroll
+        for (int i = 0; i < 10; i++) { out_re[i] = rre[i]; out_im[i] = rim[i]; }
+    } else {
+        solve_poly_generic(coeffs_in, n, out_re, out_im);
+    }
     for (int i = 0; i < n; i++)
-        if (fabs(rim[i * DK_T]) < 1e-100) rim[i * DK_T] = 0;
-    for (; n < 10; n++) { rre[n * DK_T] = rre[(n - 1) * DK_T]; rim[n * DK_T] = rim[(n - 1) * DK_T]; }
+        if (fabs(out_im[i]) < 1e-100) out_im[i] = 0;
+    for (; n < 10; n++) { out_re[n] = out_re[n - 1]; out_im[n] = out_im[n - 1]; }
 }
 
 // EMEstimatorCallback::runKernel.  x1,x2: 5 normalised correspondences.  Writes up to 10
 // models (row-major, unit Frobenius norm, x2^T E x1 = 0) to Ebuf; returns their number.
-__device__ int five_point(const double* x1, const double* x2, double* Ebuf, double* coef, double* rre, double* rim) {
+__device__ int five_point(const double* x1, const double* x2, double* Ebuf) {
     double At[9 * 9];
     for (int i = 0; i < 81; i++) At[i] = 0;
     for (int i = 0; i < 5; i++) {
@@ -343,11 +415,12 @@ __device__ int five_point(const double* x1, const double* x2, double* Ebuf, doub
         const double sgn = (r == 1) ? -1.0 : 1.0;
         for (int k = 0; k <= 10; k++) cdet[k] += sgn * term[k];
     }
-    solve_poly10(cdet, coef, rre, rim);
+    double rre[10], rim[10];
+    solve_poly10(cdet, rre, rim);
     int count = 0;
     for (int i = 0; i < 10; i++) {
-        if (fabs(rim[i * DK_T]) > 1e-10) continue;
-        const double z1 = rre[i * DK_T], z2 = z1 * z1, z3 = z2 * z1, z4 = z3 * z1;
+        if (fabs(rim[i]) > 1e-10) continue;
+        const double z1 = rre[i], z2 = z1 * z1, z3 = z2 * z1, z4 = z3 * z1;
         double bz[9];
         for (int j = 0; j < 3; j++) {
             const double* br = b[j];
@@ -450,7 +523,6 @@ __global__ void k_ransac_sample(PoseWork* pw, const int* __restrict__ nmatch, in
 __global__ __launch_bounds__(DK_T) void k_ransac_solve(const PoseWork* __restrict__ pw, const int* __restrict__ nmatch, int P, int kp_cap,
                                                        const float2* __restrict__ q1, const float2* __restrict__ q2, NormK nk,
                                                        const int* __restrict__ samples, double* __restrict__ models, int* __restrict__ nmodels) {
-    __shared__ double s_coef[11 * DK_T], s_rre[10 * DK_T], s_rim[10 * DK_T];
     const int p = blockIdx.y, h = blockIdx.x * DK_T + threadIdx.x;
     const PoseWork& w = pw[p];
     if (w.done) return;
@@ -465,7 +537,7 @@ __global__ __launch_bounds__(DK_T) void k_ransac_solve(const PoseWork* __restric
         norm_pt(nk, q2[o], x2[2 * i], x2[2 * i + 1]);
     }
     double Eb[90];
-    const int nm = five_point(x1, x2, Eb, s_coef + threadIdx.x, s_rre + threadIdx.x, s_rim + threadIdx.x);
+    const int nm = five_point(x1, x2, Eb);
     nmodels[ho] = nm;
     double* mo = models + ho * 90;
     for (int i = 0; i < nm * 9; i++) mo[i] = Eb[i];

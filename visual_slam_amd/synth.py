@@ -47,24 +47,37 @@ def relative_pose(yaw_deg=0.5, forward=1.0):
     return R, -R @ C
 
 
+_WARP_CACHE = {}
+
+
+def _warp_maps(w, h, K):
+    """Seed-independent sampling positions of frame B in frame A (cached per geometry)."""
+    key = (w, h, K.tobytes())
+    if key not in _WARP_CACHE:
+        R, t = relative_pose()
+        u, v = np.meshgrid(np.arange(w, dtype=np.float64), np.arange(h, dtype=np.float64))
+        dx = (u - K[0, 2]) / K[0, 0]
+        dy = (v - K[1, 2]) / K[1, 1]
+        depth = np.where(dy > 1.65 / 30.0, 1.65 / np.maximum(dy, 1e-9), 30.0)   # ground plane below, wall above
+        XB = np.stack([dx * depth, dy * depth, depth], -1)
+        XA = (XB - t) @ R        # R^T (X_B - t)
+        ua = K[0, 0] * XA[..., 0] / XA[..., 2] + K[0, 2]
+        va = K[1, 1] * XA[..., 1] / XA[..., 2] + K[1, 2]
+        ua = np.clip(ua, 0, w - 1.001); va = np.clip(va, 0, h - 1.001)
+        x0 = np.floor(ua).astype(np.int64); y0 = np.floor(va).astype(np.int64)
+        fx = (ua - x0).astype(np.float32); fy = (va - y0).astype(np.float32)
+        i00 = (y0 * w + x0).ravel()
+        _WARP_CACHE[key] = (i00, fx.ravel(), fy.ravel())
+    return _WARP_CACHE[key]
+
+
 def warp_b(img_a, K):
     h, w = img_a.shape
-    R, t = relative_pose()
-    u, v = np.meshgrid(np.arange(w, dtype=np.float64), np.arange(h, dtype=np.float64))
-    dx = (u - K[0, 2]) / K[0, 0]
-    dy = (v - K[1, 2]) / K[1, 1]
-    depth = np.where(dy > 1.65 / 30.0, 1.65 / np.maximum(dy, 1e-9), 30.0)   # ground plane below, wall above
-    XB = np.stack([dx * depth, dy * depth, depth], -1)
-    XA = (XB - t) @ R        # R^T (X_B - t)
-    ua = K[0, 0] * XA[..., 0] / XA[..., 2] + K[0, 2]
-    va = K[1, 1] * XA[..., 1] / XA[..., 2] + K[1, 2]
-    ua = np.clip(ua, 0, w - 1.001); va = np.clip(va, 0, h - 1.001)
-    x0 = np.floor(ua).astype(np.int64); y0 = np.floor(va).astype(np.int64)
-    fx = (ua - x0).astype(np.float32); fy = (va - y0).astype(np.float32)
-    a = img_a.astype(np.float32)
-    top = a[y0, x0] * (1 - fx) + a[y0, x0 + 1] * fx
-    bot = a[y0 + 1, x0] * (1 - fx) + a[y0 + 1, x0 + 1] * fx
-    return np.clip(np.rint(top * (1 - fy) + bot * fy), 0, 255).astype(np.uint8)
+    i00, fx, fy = _warp_maps(w, h, np.ascontiguousarray(K, np.float64))
+    a = img_a.astype(np.float32).ravel()
+    top = a[i00] * (1 - fx) + a[i00 + 1] * fx
+    bot = a[i00 + w] * (1 - fx) + a[i00 + w + 1] * fx
+    return np.clip(np.rint(top * (1 - fy) + bot * fy), 0, 255).astype(np.uint8).reshape(h, w)
 
 
 def make_pair(seed, w=1241, h=376, K=None):
