@@ -78,7 +78,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
-    from visual_slam_amd import _lib, synth
+    from visual_slam_amd import _lib, parallel, synth
 
     B = args.pairs
     workers = args.workers if args.workers > 0 else max(1, min(12, (os.cpu_count() or 1) // max(world, 1)))
@@ -94,7 +94,10 @@ def main():
     ctx = _lib.Context(max_w=W_IMG, max_h=H_IMG, chunk_pairs=min(args.chunk, B), max_pairs=B, device=local_rank)
 
     def step():
-        return ctx.pairs_run_device(dA.data_ptr(), dB.data_ptr(), B, W_IMG, H_IMG, W_IMG, K)
+        # this rank's shard of the job, then (N > 1) the only collective of the path: an RCCL
+        # all_gather of the 152-byte per-pair result records
+        local = ctx.pairs_run_device(dA.data_ptr(), dB.data_ptr(), B, W_IMG, H_IMG, W_IMG, K)
+        return parallel.gather_pair_results(local, world * B) if world > 1 else local
 
     def barrier():
         if world > 1:
@@ -110,10 +113,7 @@ def main():
         res = step()
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = parallel.max_over_ranks(dt)
     ok = int((res["status"] == 0).sum())
 
     # per-kernel durations: HIP events around every launch on the launch stream (diagnostic pass,
@@ -140,7 +140,7 @@ def main():
                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
                     "bytes_per_launch": int(bytes_per_launch), "avg_launch_ms": hbm[dom]["avg_ms"]}
         if "k_match" in kernels:
-            nk = res["n_kp1"].astype(np.float64) * res["n_kp2"].astype(np.float64)
+            nk = res["n_kp1"][:B].astype(np.float64) * res["n_kp2"][:B].astype(np.float64)
             ops = float(nk.sum()) * 16.0
             roofline["matcher"] = {"bound": "valu-int", "achieved_Tlaneops": round(ops / (kernels["k_match"]["ms_total"] * 1e-3) / 1e12, 3),
                                    "peak_Tlaneops": round(VALU_PEAK_TOPS, 2)}
@@ -158,7 +158,7 @@ def main():
             "dtype": "u8/int32 detect+match, f64 pose", "data": "synthetic",
             "config": {"workload": "configs[2]: batch of synthetic 1241x376 pairs (configs[1] generator, seeds 0..), 3000 ORB features, 8 levels",
                        "pairs_per_gpu": B, "distinct_pairs_per_gpu": nd, "global_pairs": world * B, "chunk_pairs": min(args.chunk, B), "parallelism": "pairs sharded over ranks, no collective",
-                       "pairs_ok": ok},
+                       "pairs_ok": ok, "pairs_total": int(len(res))},
             "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels,
         }
         print(json.dumps(out))

@@ -151,3 +151,27 @@ def test_dropin_visual_odometry(oracle, K02):
     assert np.abs(pb - ref).max() / np.abs(ref).max() < 1e-5
     with pytest.raises(NotImplementedError):
         vo.get_matches(1, "SIFT", None, None)
+
+
+def test_config4_4k_20k_features(oracle):
+    """BASELINE.json configs[3]: 3840x2160 synthetic pair, 20k ORB features (O(N^2) matcher stress)."""
+    from visual_slam_amd import _lib, synth
+    a, b, K, R, t = synth.make_pair(1, 3840, 2160)
+    p = oracle.default_params(nfeatures=20000)
+    k1, f1 = oracle.orb_detect_compute(a, p)
+    k2, f2 = oracle.orb_detect_compute(b, p)
+    assert len(k1) >= 20000 and len(k2) >= 20000
+    c = _lib.Context(max_w=3840, max_h=2160, nfeatures=20000)
+    g1, d1 = c.orb_detect_compute(a)
+    g2, d2 = c.orb_detect_compute(b)
+    assert np.array_equal(g1.view(np.uint8), k1.view(np.uint8)) and np.array_equal(d1, f1)
+    assert np.array_equal(g2.view(np.uint8), k2.view(np.uint8)) and np.array_equal(d2, f2)
+    oi1, od1, oi2, od2 = oracle.match_knn2(f1, f2)
+    gi1, gd1, gi2, gd2 = c.match_knn2(d1, d2)
+    assert np.array_equal(gi1, oi1) and np.array_equal(gd1, od1) and np.array_equal(gi2, oi2) and np.array_equal(gd2, od2)
+    res = c.pairs_run(a[None], b[None], K)[0]
+    rc, T, counts = oracle.pair_run(a, b, K, p=p)
+    c.close()
+    assert rc == 0 and res["status"] == 0
+    assert [res["n_kp1"], res["n_kp2"], res["n_match"], res["n_inlier"]] == counts.tolist()
+    assert rot_angle(T[:3, :3], res["T"][:3, :3]) < 1e-6 and dir_angle(T[:3, 3], res["T"][:3, 3]) < 1e-6

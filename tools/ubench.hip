@@ -1,0 +1,51 @@
+// micro-benchmark: issue rate of v_bcnt_u32_b32 / v_xor / v_add on gfx950
+#include <hip/hip_runtime.h>
+#include <cstdio>
+template <int MODE>
+__global__ __launch_bounds__(256) void k(uint32_t* out, uint32_t seed, int iters, const uint32_t* __restrict__ u) {
+    uint32_t a[8], acc[8];
+    for (int i = 0; i < 8; i++) { a[i] = seed * (threadIdx.x + i + 1); acc[i] = i; }
+    for (int it = 0; it < iters; it++) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            if (MODE == 0) acc[i] = __popc(a[i] ^ acc[i]) + acc[i];       // xor + bcnt(acc)
+            if (MODE == 1) acc[i] = (a[i] ^ acc[i]) + acc[i];              // xor + add
+            if (MODE == 2) acc[i] = __popc(a[i]) + acc[i];                 // bcnt only
+            if (MODE == 3) acc[i] = a[i] + acc[i] * 3u;                    // mad-ish
+            if (MODE == 4) acc[i] = (u[(it & 7) * 8 + i] ^ a[i]) + acc[i];    // xor with SGPR operand + add
+            if (MODE == 5) acc[i] = __popc(u[(it & 7) * 8 + i] ^ a[i]) + acc[i]; // xor(SGPR) + bcnt(acc)
+            if (MODE == 6) acc[i] = min(a[i], acc[i]) + 1;                // min + add
+        }
+    }
+    uint32_t s = 0;
+    for (int i = 0; i < 8; i++) s += acc[i];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+template <int MODE>
+void run(const char* name, int ops) {
+    uint32_t* d;
+    hipMalloc(&d, 256 * 8 * 256 * 4 * 4);
+    const int blocks = 256 * 8, iters = 4096;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(256), 0, 0, d, 12345u, iters, (const uint32_t*)d);
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(256), 0, 0, d, 12345u, iters, (const uint32_t*)d);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    double laneops = (double)blocks * 256 * iters * 8 * ops;
+    printf("%-12s %.3f ms  %.2f T lane-instr/s\n", name, ms, laneops / (ms * 1e-3) / 1e12);
+    hipFree(d);
+}
+int main() {
+    run<0>("xor+bcnt", 2);
+    run<1>("xor+add", 2);
+    run<2>("bcnt", 1);
+    run<3>("mad", 1);
+    run<4>("xorS+add", 2);
+    run<5>("xorS+bcnt", 2);
+    run<6>("min+add", 2);
+    return 0;
+}
