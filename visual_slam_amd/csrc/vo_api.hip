@@ -113,7 +113,7 @@ static int ctx_init(vo_ctx* c) {
             if (l > 0) pyr += (pitch * h + 255) / 256 * 256;
             blur += (pitch * h + 255) / 256 * 256;
             const long iw = std::max(w - 62, 0L), ih = std::max(h - 62, 0L);
-            const long ntx = (iw + 31) / 32, nty = (ih + 31) / 32;
+            const long ntx = (iw + VO_TILE_W - 1) / VO_TILE_W, nty = (ih + VO_TILE_H - 1) / VO_TILE_H;
             tiles += ntx * nty;
             segs += (ih * ntx + 15) / 16 * 16;
             cand += (((iw + 1) / 2) * ((ih + 1) / 2) + 63) / 64 * 64;

@@ -19,6 +19,7 @@
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 #include "vo_internal.h"
@@ -74,8 +75,8 @@ int vo_build_geometry(vo_ctx* c, int w, int h) {
         bool has = (L.w > 2 * VO_EDGE) && (L.h > 2 * VO_EDGE);
         L.iw = has ? L.w - 2 * VO_EDGE : 0;
         L.ih = has ? L.h - 2 * VO_EDGE : 0;
-        L.ntx = (L.iw + VO_TILE - 1) / VO_TILE;
-        L.nty = (L.ih + VO_TILE - 1) / VO_TILE;
+        L.ntx = (L.iw + VO_TILE_W - 1) / VO_TILE_W;
+        L.nty = (L.ih + VO_TILE_H - 1) / VO_TILE_H;
         L.tile_base = tile_base;
         tile_base += L.ntx * L.nty;
         L.seg_base = seg_base;
@@ -200,139 +201,223 @@ __global__ __launch_bounds__(256) void k_pyramid(const Geom* __restrict__ g, Fra
 //   darker  arc of 9 all < v-t   <=>  min over the 16 arcs of (max over the arc of p) < v - t
 //   brighter arc of 9 all > v+t  <=>  max over the 16 arcs of (min over the arc of p) > v + t
 // and cornerScore<16> = max(v - min_arcs max9(p), max_arcs min9(p) - v) - 1.
-#define PXP 48  // LDS pixel tile pitch
+#define PXP 80  // LDS pixel tile pitch (18 dwords loaded; runs of 4 positions read up to column 75)
 #define PXO 3   // column of the LDS tile that holds image column x0-4 (the tile is loaded from a dword boundary)
+#define PXR 38  // LDS pixel tile rows: 30 outputs + 2 ring + 2*3
+#define SCP 64  // score tile pitch: 64 x 32 positions, (0,0) = image (x0-1, y0-1)
 // circle offsets k = 0..15 as (dx,dy): (0,3)(1,3)(2,2)(3,1)(3,0)(3,-1)(2,-2)(1,-3)(0,-3)(-1,-3)(-2,-2)(-3,-1)(-3,0)(-3,1)(-2,2)(-1,3)
 #define CIRC(k) (((k) == 0 ? 3 : (k) == 1 ? 3 : (k) == 2 ? 2 : (k) == 3 ? 1 : (k) == 4 ? 0 : (k) == 5 ? -1 : (k) == 6 ? -2 : (k) == 7 ? -3 : \
                   (k) == 8 ? -3 : (k) == 9 ? -3 : (k) == 10 ? -2 : (k) == 11 ? -1 : (k) == 12 ? 0 : (k) == 13 ? 1 : (k) == 14 ? 2 : 3) * PXP + \
                  ((k) == 0 ? 0 : (k) == 1 ? 1 : (k) == 2 ? 2 : (k) == 3 ? 3 : (k) == 4 ? 3 : (k) == 5 ? 3 : (k) == 6 ? 2 : (k) == 7 ? 1 : \
                   (k) == 8 ? 0 : (k) == 9 ? -1 : (k) == 10 ? -2 : (k) == 11 ? -3 : (k) == 12 ? -3 : (k) == 13 ? -3 : (k) == 14 ? -2 : -1))
 
-// 0 for a non-corner, else cornerScore<16> (largest threshold that keeps it a corner, minus 1)
-__device__ __forceinline__ int fast_score_lds(const uint8_t* p, int thr) {
-    const int v = p[0];
+// max over the 16 arcs of 9 of (min over the arc) [BRIGHT] or min over the arcs of (max over the arc) [!BRIGHT];
+// arcs of 9 as three arcs of 3, all in 3-operand min/max: 40 VALU ops per polarity
+template <bool BRIGHT>
+__device__ __forceinline__ int fast_arc_extreme(const uint8_t* p) {
     int x[16];
 #pragma unroll
     for (int k = 0; k < 16; k++) x[k] = p[CIRC(k)];
-    int lo2[16], hi2[16];
+    int e3[16];
 #pragma unroll
-    for (int k = 0; k < 16; k++) { lo2[k] = min(x[k], x[(k + 1) & 15]); hi2[k] = max(x[k], x[(k + 1) & 15]); }
-    int lo4[16], hi4[16];
+    for (int k = 0; k < 16; k++)
+        e3[k] = BRIGHT ? min(min(x[k], x[(k + 1) & 15]), x[(k + 2) & 15]) : max(max(x[k], x[(k + 1) & 15]), x[(k + 2) & 15]);
+    int e9[16];
 #pragma unroll
-    for (int k = 0; k < 16; k++) { lo4[k] = min(lo2[k], lo2[(k + 2) & 15]); hi4[k] = max(hi2[k], hi2[(k + 2) & 15]); }
-    int maxmin = 0, minmax = 255;
+    for (int k = 0; k < 16; k++)
+        e9[k] = BRIGHT ? min(min(e3[k], e3[(k + 3) & 15]), e3[(k + 6) & 15]) : max(max(e3[k], e3[(k + 3) & 15]), e3[(k + 6) & 15]);
+    int best = e9[15];
 #pragma unroll
-    for (int k = 0; k < 16; k++) {
-        const int lo9 = min(min(lo4[k], lo4[(k + 4) & 15]), x[(k + 8) & 15]);
-        const int hi9 = max(max(hi4[k], hi4[(k + 4) & 15]), x[(k + 8) & 15]);
-        maxmin = max(maxmin, lo9);
-        minmax = min(minmax, hi9);
-    }
-    const int best = max(v - minmax, maxmin - v);  // largest t' with all of some arc differing by >= t'
-    return best > thr ? best - 1 : 0;
+    for (int k = 0; k < 14; k += 2) best = BRIGHT ? max(max(best, e9[k]), e9[k + 1]) : min(min(best, e9[k]), e9[k + 1]);
+    return BRIGHT ? max(best, e9[14]) : min(best, e9[14]);
 }
 
+// byte k (0..3) of dword d
+#define BYTE(d, k) (((d) >> (8 * (k))) & 0xFFu)
+
+// inclusive prefix sum over the 64 lanes of a wavefront with DPP row shifts / row broadcasts (6 VALU ops)
+__device__ __forceinline__ int wave_incl_scan(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);  // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);  // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);  // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);  // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);  // row_bcast:31 into rows 2 and 3
+    return v;
+}
+__device__ __forceinline__ int lanes_below(unsigned long long m) {
+    return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+
+#define FQ_CAP 4096
+template <int ABL>
 __global__ __launch_bounds__(256) void k_fast_tiles(const Geom* __restrict__ g, FrameSrc src, const uint8_t* __restrict__ pyr,
                                                     const TileDesc* __restrict__ tiles, uint32_t* __restrict__ tile_list,
                                                     uint8_t* __restrict__ seg_cnt) {
-    __shared__ __attribute__((aligned(16))) uint8_t px[40 * PXP];
-    __shared__ uint8_t sc[34 * 36];
-    __shared__ uint16_t queue[34 * 34];
-    __shared__ int wtot[4], qn;
+    __shared__ __attribute__((aligned(16))) uint8_t px[PXR * PXP];
+    __shared__ __attribute__((aligned(16))) uint8_t sc[32 * SCP + 8];      // scores of the 64 x 32 positions
+    __shared__ __attribute__((aligned(16))) uint8_t km[32 * 64];           // kept (NMS + border) scores of the 60 x 30 outputs
+    __shared__ uint16_t queue[FQ_CAP];   // brighter-arc candidates from the front, darker-arc candidates from the back
+    __shared__ int wtot[4], qcnt;        // qcnt: brighter count | darker count << 16
     const int t = blockIdx.x, f = blockIdx.y, tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const TileDesc td = tiles[t];
     const LevelGeom& L = g->lv[td.level];
+    const int Lw = L.w, Lh = L.h;
     int pitch;
     const uint8_t* img = level_ptr(g, src, pyr, f, td.level, pitch);
-    const int x0 = VO_EDGE + td.tx * VO_TILE, y0 = VO_EDGE + td.ty * VO_TILE;
-    // 40 rows x 44 bytes from the dword boundary xa = x0-4-PXO (a multiple of 4), as 11 dwords per row
+    const int x0 = VO_EDGE + td.tx * VO_TILE_W, y0 = VO_EDGE + td.ty * VO_TILE_H;
+    // 38 rows x 72 bytes from the dword boundary xa = x0-4-PXO (a multiple of 4), as 18 dwords per row;
+    // 252 lanes cover 14 rows per pass
     const int xa = x0 - 4 - PXO;
-    if (tid == 0) qn = 0;
-    for (int i = tid; i < 40 * 11; i += 256) {
-        const int r = i / 11, k = i - r * 11;
-        const int y = min(y0 - 4 + r, L.h - 1), x = xa + 4 * k;
-        const uint8_t* rp = img + (long)y * pitch;
-        uint32_t v;
-        if (x + 3 < L.w) {
-            __builtin_memcpy(&v, rp + x, 4);  // level 0 rows may be unaligned (caller's stride)
-        } else {
-            v = 0;
+    if (tid == 0) qcnt = 0;
+    if (tid < 252) {
+        const int r0 = tid / 18, k = tid - r0 * 18;
+        const int x = xa + 4 * k;
+        const bool whole = x + 3 < Lw;
 #pragma unroll
-            for (int j = 0; j < 4; j++) v |= (uint32_t)rp[min(x + j, L.w - 1)] << (8 * j);
+        for (int pass = 0; pass < 3; pass++) {
+            const int r = r0 + 14 * pass;
+            if (r < PXR) {
+                const int y = min(y0 - 4 + r, Lh - 1);
+                const uint8_t* rp = img + (long)y * pitch;
+                uint32_t v;
+                if (whole) {
+                    __builtin_memcpy(&v, rp + x, 4);  // level 0 rows may be unaligned (caller's stride)
+                } else {
+                    v = 0;
+#pragma unroll
+                    for (int j = 0; j < 4; j++) v |= (uint32_t)rp[min(x + j, Lw - 1)] << (8 * j);
+                }
+                *reinterpret_cast<uint32_t*>(&px[r * PXP + 4 * k]) = v;
+            }
         }
-        *reinterpret_cast<uint32_t*>(&px[r * PXP + 4 * k]) = v;
     }
     __syncthreads();
     const int thr = g->fast_threshold;
-    // Stage 1 (every position): a 9-arc contains one pixel of every opposite pair, so with the
-    // four even pairs  min_k max(p_k, p_k+8) > v+t  or  max_k min(p_k, p_k+8) < v-t  is necessary.
-    // Survivors are queued so that stage 2 (all 16 arcs + score) runs on dense wavefronts.
-    for (int i0 = 0; i0 < 34 * 34; i0 += 256) {
-        const int i = i0 + tid;
-        bool pass = false;
-        if (i < 34 * 34) {
-            const int r = i / 34, c = i - r * 34;
-            const int xi = x0 - 1 + c, yi = y0 - 1 + r;
-            sc[r * 36 + c] = 0;
-            if (xi < L.w - 3 && yi < L.h - 3) {
-                const uint8_t* p = &px[(r + 3) * PXP + c + 3 + PXO];
-                const int v = p[0];
-                const int a0 = p[CIRC(0)], a8 = p[CIRC(8)], a2 = p[CIRC(2)], a10 = p[CIRC(10)];
-                const int a4 = p[CIRC(4)], a12 = p[CIRC(12)], a6 = p[CIRC(6)], a14 = p[CIRC(14)];
-                const int mm = min(min(max(a0, a8), max(a2, a10)), min(max(a4, a12), max(a6, a14)));
-                const int xm = max(max(min(a0, a8), min(a2, a10)), max(min(a4, a12), min(a6, a14)));
-                pass = (mm > v + thr) || (xm < v - thr);
-            }
-        }
-        const unsigned long long m = __ballot(pass);
+    if (ABL == 3) return;
+    // Stage 1: every score position (64 x 32), 4 adjacent positions per lane and iteration, read as
+    // aligned LDS dwords.  Score column c <-> LDS column c+6, score row r <-> LDS row r+3.
+    // A 9-arc contains one pixel of every opposite pair, so with the four even pairs
+    //   min_k max(p_k, p_k+8) > v+t   (brighter)   or   max_k min(p_k, p_k+8) < v-t   (darker)  is necessary.
+    // Survivors go to a brighter and/or a darker queue so that stage 2 runs dense, polarity-uniform
+    // wavefronts; one LDS atomic per wavefront and iteration reserves the queue space.
+    const int cmax = min(VO_TILE_W + 2, Lw - 3 - (x0 - 1));   // FAST is defined 3 px inside the level
+    const int rmax = Lh - 3 - (y0 - 1);
+#pragma unroll
+    for (int it = 0; it < (ABL == 2 ? 0 : 2); it++) {
+        const int run = tid + 256 * it;          // 16 runs per row
+        const int r = run >> 4, k4 = (run & 15) * 4;
+        const uint32_t* rowC = reinterpret_cast<const uint32_t*>(&px[(r + 3) * PXP + k4]);
+        const uint32_t* rowP2 = reinterpret_cast<const uint32_t*>(&px[(r + 5) * PXP + k4]);
+        const uint32_t* rowM2 = reinterpret_cast<const uint32_t*>(&px[(r + 1) * PXP + k4]);
+        const uint32_t* rowP3 = reinterpret_cast<const uint32_t*>(&px[(r + 6) * PXP + k4]);
+        const uint32_t* rowM3 = reinterpret_cast<const uint32_t*>(&px[(r + 0) * PXP + k4]);
+        const uint32_t C0 = rowC[0], C1 = rowC[1], C2 = rowC[2], C3 = rowC[3];
+        const uint32_t P21 = rowP2[1], P22 = rowP2[2], M21 = rowM2[1], M22 = rowM2[2];
+        const uint32_t P31 = rowP3[1], P32 = rowP3[2], M31 = rowM3[1], M32 = rowM3[2];
+        *reinterpret_cast<uint32_t*>(&sc[r * SCP + k4]) = 0;
+        *reinterpret_cast<uint32_t*>(&km[r * 64 + k4]) = 0;
+        // position i: centre = LDS col k4+6+i;  mm = min over pairs of max, xm = max over pairs of min
+#define PRETEST(i, v, a0, a8, a2, a10, a4, a12, a6, a14)                                                             \
+        const int mm##i = (int)min(min(max(a0, a8), max(a2, a10)), min(max(a4, a12), max(a6, a14)));                  \
+        const int xm##i = (int)max(max(min(a0, a8), min(a2, a10)), max(min(a4, a12), min(a6, a14)));                  \
+        const int th##i = (r < rmax && k4 + i < cmax) ? thr : 4096;                                                   \
+        const bool pb##i = mm##i > (int)(v) + th##i, pd##i = xm##i < (int)(v) - th##i;                                  \
+        const unsigned long long mb##i = __ballot(pb##i), md##i = __ballot(pd##i);
+        PRETEST(0, BYTE(C1, 2), BYTE(P31, 2), BYTE(M31, 2), BYTE(P22, 0), BYTE(M21, 0), BYTE(C2, 1), BYTE(C0, 3), BYTE(M22, 0), BYTE(P21, 0))
+        PRETEST(1, BYTE(C1, 3), BYTE(P31, 3), BYTE(M31, 3), BYTE(P22, 1), BYTE(M21, 1), BYTE(C2, 2), BYTE(C1, 0), BYTE(M22, 1), BYTE(P21, 1))
+        PRETEST(2, BYTE(C2, 0), BYTE(P32, 0), BYTE(M32, 0), BYTE(P22, 2), BYTE(M21, 2), BYTE(C2, 3), BYTE(C1, 1), BYTE(M22, 2), BYTE(P21, 2))
+        PRETEST(3, BYTE(C2, 1), BYTE(P32, 1), BYTE(M32, 1), BYTE(P22, 3), BYTE(M21, 3), BYTE(C3, 0), BYTE(C1, 2), BYTE(M22, 3), BYTE(P21, 3))
+#undef PRETEST
+        const int nb0 = (int)__popcll(mb0), nb1 = (int)__popcll(mb1), nb2 = (int)__popcll(mb2), nb3 = (int)__popcll(mb3);
+        const int nd0 = (int)__popcll(md0), nd1 = (int)__popcll(md1), nd2 = (int)__popcll(md2), nd3 = (int)__popcll(md3);
+        const int add = (nb0 + nb1 + nb2 + nb3) | ((nd0 + nd1 + nd2 + nd3) << 16);
         int base = 0;
-        if (lane == 0 && m) base = atomicAdd(&qn, (int)__popcll(m));
-        base = __shfl(base, 0);
-        if (pass) queue[base + (int)__popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)i;
+        if (lane == 0) base = atomicAdd(&qcnt, add);
+        base = __builtin_amdgcn_readfirstlane(base);
+        const int ob = base & 0xFFFF, od = FQ_CAP - 1 - (base >> 16);
+        const int pos = r * 64 + k4;
+        if (pb0) queue[ob + lanes_below(mb0)] = (uint16_t)pos;
+        if (pb1) queue[ob + nb0 + lanes_below(mb1)] = (uint16_t)(pos + 1);
+        if (pb2) queue[ob + nb0 + nb1 + lanes_below(mb2)] = (uint16_t)(pos + 2);
+        if (pb3) queue[ob + nb0 + nb1 + nb2 + lanes_below(mb3)] = (uint16_t)(pos + 3);
+        if (pd0) queue[od - lanes_below(md0)] = (uint16_t)pos;
+        if (pd1) queue[od - nd0 - lanes_below(md1)] = (uint16_t)(pos + 1);
+        if (pd2) queue[od - nd0 - nd1 - lanes_below(md2)] = (uint16_t)(pos + 2);
+        if (pd3) queue[od - nd0 - nd1 - nd2 - lanes_below(md3)] = (uint16_t)(pos + 3);
     }
     __syncthreads();
-    const int nq = qn;
-    for (int q = tid; q < nq; q += 256) {
+    // Stage 2: arc extremes + cornerScore of the queued positions.  A position in both queues (an edge
+    // through the centre) takes the larger of its two scores: the darker pass runs after a barrier.
+    const int nb = ABL == 1 ? 0 : (qcnt & 0xFFFF), nd = ABL == 1 ? 0 : (qcnt >> 16);
+    for (int q = tid; q < nb; q += 256) {
         const int i = queue[q];
-        const int r = i / 34, c = i - r * 34;
-        sc[r * 36 + c] = (uint8_t)fast_score_lds(&px[(r + 3) * PXP + c + 3 + PXO], thr);
+        const int r = i >> 6, c = i & 63;
+        const uint8_t* p = &px[(r + 3) * PXP + c + 3 + PXO];
+        const int best = fast_arc_extreme<true>(p) - (int)p[0];
+        sc[i] = (uint8_t)(best > thr ? best - 1 : 0);
     }
     __syncthreads();
-    // 3x3 non-max suppression (strict) + border filter; thread = 4 adjacent pixels of one row
-    const int r = tid >> 3, c4 = (tid & 7) * 4;
-    const int yi = y0 + r;
-    uint32_t ent[2] = {0, 0};
-    int cnt = 0;
-    if (yi < L.h - VO_EDGE) {
+    for (int q = tid; q < nd; q += 256) {
+        const int i = queue[FQ_CAP - 1 - q];
+        const int r = i >> 6, c = i & 63;
+        const uint8_t* p = &px[(r + 3) * PXP + c + 3 + PXO];
+        const int best = (int)p[0] - fast_arc_extreme<false>(p);
+        sc[i] = (uint8_t)max((int)sc[i], best > thr ? best - 1 : 0);
+    }
+    __syncthreads();
+    // Stage 3: strict 3x3 non-max suppression + border filter, only at the queued positions
+    for (int q = tid; q < nb + nd; q += 256) {
+        const int i = q < nb ? queue[q] : queue[FQ_CAP - 1 - (q - nb)];
+        const int r = i >> 6, c = i & 63;                      // score position; output (r-1, c-1)
+        const uint8_t* s0 = &sc[i];
+        const int s = s0[0];
+        const int xi = x0 - 1 + c, yi = y0 - 1 + r;
+        if (s != 0 && r >= 1 && r <= VO_TILE_H && c >= 1 && c <= VO_TILE_W && xi < Lw - VO_EDGE && yi < Lh - VO_EDGE &&
+            s > s0[-1] && s > s0[1] && s > s0[-SCP - 1] && s > s0[-SCP] && s > s0[-SCP + 1] && s > s0[SCP - 1] && s > s0[SCP] && s > s0[SCP + 1])
+            km[(r - 1) * 64 + (c - 1)] = (uint8_t)s;
+    }
+    __syncthreads();
+    // Stage 4: ordered compaction.  A lane takes 4 adjacent pixels of output rows tid/16 and 16 + tid/16
+    // (16 groups per row), so (row block, tid) order is raster order; both blocks share one packed scan.
+    uint32_t ent[2][2];
+    int cnt[2];
+#pragma unroll
+    for (int it = 0; it < 2; it++) {
+        const int r = it * 16 + (tid >> 4), c4 = (tid & 15) * 4;
+        const uint32_t kd = *reinterpret_cast<const uint32_t*>(&km[r * 64 + c4]);
+        cnt[it] = 0;
+        ent[it][0] = ent[it][1] = 0;
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            int c = c4 + j, xi = x0 + c;
-            const uint8_t* q = &sc[(r + 1) * 36 + c + 1];
-            int s = q[0];
-            bool keep = s != 0 && xi < L.w - VO_EDGE && s > q[-1] && s > q[1] && s > q[-37] && s > q[-36] && s > q[-35] && s > q[35] &&
-                        s > q[36] && s > q[37];
-            if (keep && cnt < 2) ent[cnt++] = PACK_XYS(xi, yi, s);
+            const uint32_t sv = BYTE(kd, j);
+            if (sv != 0 && cnt[it] < 2) ent[it][cnt[it]++] = PACK_XYS(x0 + c4 + j, y0 + r, sv);
         }
     }
-    int incl = cnt;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        int v = __shfl_up(incl, o);
-        if (lane >= o) incl += v;
-    }
+    const int incl = wave_incl_scan(cnt[0] | (cnt[1] << 16));
     if (lane == 63) wtot[wave] = incl;
     __syncthreads();
-    int base = 0;
-    for (int w2 = 0; w2 < wave; w2++) base += wtot[w2];
-    const int excl = base + incl - cnt;
     uint32_t* tl = tile_list + ((long)f * g->ntiles + t) * VO_TILE_CAP;
-    if (cnt > 0) tl[excl] = ent[0];
-    if (cnt > 1) tl[excl + 1] = ent[1];
-    int row_end = __shfl_down(incl, 7);
-    if ((tid & 7) == 0 && td.ty * VO_TILE + r < L.ih) {
-        int rc = row_end - (incl - cnt);
-        seg_cnt[(long)f * g->nsegs + L.seg_base + (long)(td.ty * VO_TILE + r) * L.ntx + td.tx] = (uint8_t)rc;
+    int below = 0, all = 0;
+#pragma unroll
+    for (int w2 = 0; w2 < 4; w2++) {
+        const int wt = wtot[w2];
+        all += wt;
+        if (w2 < wave) below += wt;
+    }
+    const int row_end = __shfl_down(incl, 15);
+#pragma unroll
+    for (int it = 0; it < 2; it++) {
+        const int inc = (it ? incl >> 16 : incl & 0xFFFF);
+        const int excl = (it ? (all & 0xFFFF) + (below >> 16) : (below & 0xFFFF)) + inc - cnt[it];
+        if (cnt[it] > 0) tl[excl] = ent[it][0];
+        if (cnt[it] > 1) tl[excl + 1] = ent[it][1];
+        const int r = it * 16 + (tid >> 4);
+        if ((tid & 15) == 0 && r < VO_TILE_H && td.ty * VO_TILE_H + r < L.ih) {
+            const int rc = (it ? row_end >> 16 : row_end & 0xFFFF) - (inc - cnt[it]);
+            seg_cnt[(long)f * g->nsegs + L.seg_base + (long)(td.ty * VO_TILE_H + r) * L.ntx + td.tx] = (uint8_t)rc;
+        }
     }
 }
 
@@ -393,10 +478,10 @@ __global__ __launch_bounds__(64) void k_fast_emit(const Geom* __restrict__ g, co
     const int t = blockIdx.x, f = blockIdx.y, lane = threadIdx.x;
     const TileDesc td = tiles[t];
     const LevelGeom& L = g->lv[td.level];
-    const int rows = min(VO_TILE, L.ih - td.ty * VO_TILE);
+    const int rows = min(VO_TILE_H, L.ih - td.ty * VO_TILE_H);
     int c = 0;
     if (lane < rows) {
-        long s = (long)f * g->nsegs + L.seg_base + (long)(td.ty * VO_TILE + lane) * L.ntx + td.tx;
+        long s = (long)f * g->nsegs + L.seg_base + (long)(td.ty * VO_TILE_H + lane) * L.ntx + td.tx;
         c = seg_cnt[s];
         rowofs[lane] = seg_ofs[s];
     }
@@ -610,16 +695,14 @@ __global__ __launch_bounds__(256) void k_harris(const Geom* __restrict__ g, Fram
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
         const uint32_t p = payload[cb + i];
         const uint8_t* c0 = img + (long)(UNPACK_Y(p) - 4) * pitch + (UNPACK_X(p) - 4);
-        // 9x9 window; Ix, Iy at the inner 7x7
+        // 9x9 window, each row as three (unaligned) dwords; Ix, Iy at the inner 7x7
         int a = 0, b = 0, c = 0;
-        uint8_t r0[9], r1[9], r2[9];
-#pragma unroll
-        for (int j = 0; j < 9; j++) { r0[j] = c0[j]; r1[j] = c0[pitch + j]; }
+        uint8_t r0[12], r1[12], r2[12];
+        __builtin_memcpy(r0, c0, 12);
+        __builtin_memcpy(r1, c0 + pitch, 12);
 #pragma unroll
         for (int y = 1; y <= 7; y++) {
-            const uint8_t* rp = c0 + (long)(y + 1) * pitch;
-#pragma unroll
-            for (int j = 0; j < 9; j++) r2[j] = rp[j];
+            __builtin_memcpy(r2, c0 + (long)(y + 1) * pitch, 12);
 #pragma unroll
             for (int x = 1; x <= 7; x++) {
                 int Ix = ((int)r1[x + 1] - (int)r1[x - 1]) * 2 + ((int)r0[x + 1] - (int)r0[x - 1]) + ((int)r2[x + 1] - (int)r2[x - 1]);
@@ -629,7 +712,7 @@ __global__ __launch_bounds__(256) void k_harris(const Geom* __restrict__ g, Fram
                 c += Ix * Iy;
             }
 #pragma unroll
-            for (int j = 0; j < 9; j++) { r0[j] = r1[j]; r1[j] = r2[j]; }
+            for (int j = 0; j < 12; j++) { r0[j] = r1[j]; r1[j] = r2[j]; }
         }
         const float fa = (float)a, fb = (float)b, fc = (float)c;
         const float t1 = fa * fb;
@@ -878,38 +961,56 @@ __global__ __launch_bounds__(256) void k_blur(const Geom* __restrict__ g, FrameS
 }
 
 // ------------------------------------------------------------------ rBRIEF-256, one wavefront per keypoint
+// A block takes 64 keypoints: first one lane per keypoint evaluates cos/sin (double precision,
+// rounded to float, as the oracle) so the trigonometry is not repeated by all 64 lanes of the
+// describing wave; then each of the 4 waves describes 16 keypoints, 4 test pairs per lane.
+#define RB_KPB 64
 __global__ __launch_bounds__(256) void k_rbrief(const Geom* __restrict__ g, const uint8_t* __restrict__ blur, const signed char* __restrict__ pat_g,
                                                 const int* __restrict__ nkp, const vo_keypoint* __restrict__ kps,
                                                 const uint32_t* __restrict__ kplvl, uint8_t* __restrict__ desc) {
     __shared__ __attribute__((aligned(16))) signed char pat[1024];
-    const int f = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
+    __shared__ float s_cos[RB_KPB], s_sin[RB_KPB];
+    const int f = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = nkp[f];
+    const int k0 = blockIdx.x * RB_KPB;
+    if (k0 >= n) return;
     reinterpret_cast<int*>(pat)[tid] = reinterpret_cast<const int*>(pat_g)[tid];
+    if (tid < RB_KPB && k0 + tid < n) {
+        float angle = kps[(long)f * g->kp_cap + k0 + tid].angle;
+        angle *= (float)(M_PI / 180.f);
+        s_cos[tid] = (float)cos((double)angle);
+        s_sin[tid] = (float)sin((double)angle);
+    }
     __syncthreads();
-    const int idx = blockIdx.x * 4 + (tid >> 6);
-    if (idx >= nkp[f]) return;
-    const long o = (long)f * g->kp_cap + idx;
-    const uint32_t kl = kplvl[o];
-    const int l = UNPACK_S(kl);
-    const LevelGeom& L = g->lv[l];
-    const uint8_t* center = blur + (long)f * g->blur_frame + L.blur_ofs + (long)UNPACK_Y(kl) * L.bpitch + UNPACK_X(kl);
-    float angle = kps[o].angle;
-    angle *= (float)(M_PI / 180.f);
-    const float a = (float)cos((double)angle), b = (float)sin((double)angle);
-    const int pitch = L.bpitch;
-    uint32_t nib = 0;
+    // this lane's 4 test pairs (8 pattern points)
+    float px0[4], py0[4], px1[4], py1[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         const signed char* pp = &pat[(lane * 4 + j) * 4];
-        const float x0 = (float)pp[0], y0 = (float)pp[1], x1 = (float)pp[2], y1 = (float)pp[3];
-        const float xa0 = x0 * a, yb0 = y0 * b, xb0 = x0 * b, ya0 = y0 * a;
-        const float xa1 = x1 * a, yb1 = y1 * b, xb1 = x1 * b, ya1 = y1 * a;
-        const int ix0 = __float2int_rn(xa0 - yb0), iy0 = __float2int_rn(xb0 + ya0);
-        const int ix1 = __float2int_rn(xa1 - yb1), iy1 = __float2int_rn(xb1 + ya1);
-        const int t0 = center[iy0 * pitch + ix0], t1 = center[iy1 * pitch + ix1];
-        nib |= (uint32_t)(t0 < t1) << j;
+        px0[j] = (float)pp[0]; py0[j] = (float)pp[1]; px1[j] = (float)pp[2]; py1[j] = (float)pp[3];
     }
-    const uint32_t hi = __shfl_down(nib, 1);
-    if ((lane & 1) == 0) desc[o * 32 + (lane >> 1)] = (uint8_t)(nib | (hi << 4));
+    for (int kk = wave; kk < RB_KPB; kk += 4) {
+        const int idx = k0 + kk;
+        if (idx >= n) break;
+        const long o = (long)f * g->kp_cap + idx;
+        const uint32_t kl = kplvl[o];
+        const LevelGeom& L = g->lv[UNPACK_S(kl)];
+        const int pitch = L.bpitch;
+        const uint8_t* center = blur + (long)f * g->blur_frame + L.blur_ofs + (long)UNPACK_Y(kl) * pitch + UNPACK_X(kl);
+        const float a = s_cos[kk], b = s_sin[kk];
+        uint32_t nib = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const float xa0 = px0[j] * a, yb0 = py0[j] * b, xb0 = px0[j] * b, ya0 = py0[j] * a;
+            const float xa1 = px1[j] * a, yb1 = py1[j] * b, xb1 = px1[j] * b, ya1 = py1[j] * a;
+            const int ix0 = __float2int_rn(xa0 - yb0), iy0 = __float2int_rn(xb0 + ya0);
+            const int ix1 = __float2int_rn(xa1 - yb1), iy1 = __float2int_rn(xb1 + ya1);
+            const int t0 = center[iy0 * pitch + ix0], t1 = center[iy1 * pitch + ix1];
+            nib |= (uint32_t)(t0 < t1) << j;
+        }
+        const uint32_t hi = __shfl_down(nib, 1);
+        if ((lane & 1) == 0) desc[o * 32 + (lane >> 1)] = (uint8_t)(nib | (hi << 4));
+    }
 }
 
 // ------------------------------------------------------------------ host: launch the chain
@@ -949,7 +1050,11 @@ int vo_launch_detect(vo_ctx* c, const FrameSrc& src, int F, hipStream_t st) {
         KT(c, st, VO_K_PYRAMID, hipLaunchKernelGGL(k_pyramid, grid, dim3(256), 0, st, dg, src, pyr, (const ResizeCoef*)c->d_rtab.p, l));
     }
     if (g.ntiles > 0) {
-        KT(c, st, VO_K_FAST_TILES, hipLaunchKernelGGL(k_fast_tiles, dim3(g.ntiles, F), dim3(256), 0, st, dg, src, pyr, tiles, (uint32_t*)c->d_tile_list.p, (uint8_t*)c->d_seg_cnt.p));
+        static const int abl = getenv("VO_FAST_ABLATE") ? atoi(getenv("VO_FAST_ABLATE")) : 0;   // timing experiments only
+        if (abl == 1) hipLaunchKernelGGL(k_fast_tiles<1>, dim3(g.ntiles, F), dim3(256), 0, st, dg, src, pyr, tiles, (uint32_t*)c->d_tile_list.p, (uint8_t*)c->d_seg_cnt.p);
+        if (abl == 2) hipLaunchKernelGGL(k_fast_tiles<2>, dim3(g.ntiles, F), dim3(256), 0, st, dg, src, pyr, tiles, (uint32_t*)c->d_tile_list.p, (uint8_t*)c->d_seg_cnt.p);
+        if (abl == 3) hipLaunchKernelGGL(k_fast_tiles<3>, dim3(g.ntiles, F), dim3(256), 0, st, dg, src, pyr, tiles, (uint32_t*)c->d_tile_list.p, (uint8_t*)c->d_seg_cnt.p);
+        KT(c, st, VO_K_FAST_TILES, hipLaunchKernelGGL(k_fast_tiles<0>, dim3(g.ntiles, F), dim3(256), 0, st, dg, src, pyr, tiles, (uint32_t*)c->d_tile_list.p, (uint8_t*)c->d_seg_cnt.p));
     }
     KT(c, st, VO_K_FAST_SCAN, hipLaunchKernelGGL(k_fast_scan, dim3(g.nlevels, F), dim3(256), 0, st, dg, (const uint8_t*)c->d_seg_cnt.p, (uint32_t*)c->d_seg_ofs.p, cnt_fast));
     if (g.ntiles > 0) {
@@ -966,7 +1071,7 @@ int vo_launch_detect(vo_ctx* c, const FrameSrc& src, int F, hipStream_t st) {
     BlurK bk;
     gaussian_kernel7_sigma2(bk);
     KT(c, st, VO_K_BLUR, hipLaunchKernelGGL(k_blur, dim3(g.nbtiles, F), dim3(256), 0, st, dg, src, pyr, blur, (const TileDesc*)c->d_btiles.p, bk));
-    KT(c, st, VO_K_RBRIEF, hipLaunchKernelGGL(k_rbrief, dim3((g.kp_cap + 3) / 4, F), dim3(256), 0, st, dg, blur, (const signed char*)c->d_pat.p, (const int*)c->d_nkp.p,
+    KT(c, st, VO_K_RBRIEF, hipLaunchKernelGGL(k_rbrief, dim3((g.kp_cap + RB_KPB - 1) / RB_KPB, F), dim3(256), 0, st, dg, blur, (const signed char*)c->d_pat.p, (const int*)c->d_nkp.p,
                        (const vo_keypoint*)c->d_kp.p, (const uint32_t*)c->d_kplvl.p, (uint8_t*)c->d_desc.p));
     HIP_TRY(c, hipGetLastError());
     return VO_OK;

@@ -9,8 +9,9 @@
 
 #define VO_MAX_LEVELS 8
 #define VO_EDGE 31          // runByImageBorder(edgeThreshold)
-#define VO_TILE 32          // FAST tile edge (output pixels)
-#define VO_TILE_CAP 256     // a 32x32 tile holds at most 256 strict 3x3 maxima
+#define VO_TILE_W 60        // FAST tile (output pixels): 60 x 30, i.e. a 64 x 32 score region = 2 runs of 4 per lane
+#define VO_TILE_H 30
+#define VO_TILE_CAP 512     // a 60x30 tile holds at most 30*15 = 450 strict 3x3 maxima
 #define VO_BLUR_TW 64
 #define VO_BLUR_TH 32
 

@@ -46,10 +46,13 @@ __device__ void jacobi_svd(double* At, double* W, double* Vt) {
     }
     for (int iter = 0; iter < max_iter; iter++) {
         bool changed = false;
+#pragma unroll
         for (int i = 0; i < N - 1; i++)
+#pragma unroll
             for (int j = i + 1; j < N; j++) {
                 double *Ai = At + i * M, *Aj = At + j * M;
                 double a = W[i], p = 0, b = W[j];
+#pragma unroll
                 for (int k = 0; k < M; k++) p += Ai[k] * Aj[k];
                 if (fabs(p) <= eps * sqrt(a * b)) continue;
                 p *= 2;
@@ -63,6 +66,7 @@ __device__ void jacobi_svd(double* At, double* W, double* Vt) {
                     s = p / (gamma * c * 2);
                 }
                 a = b = 0;
+#pragma unroll
                 for (int k = 0; k < M; k++) {
                     double t0 = c * Ai[k] + s * Aj[k];
                     double t1 = -s * Ai[k] + c * Aj[k];
@@ -72,6 +76,7 @@ __device__ void jacobi_svd(double* At, double* W, double* Vt) {
                 W[i] = a; W[j] = b;
                 changed = true;
                 double *Vi = Vt + i * N, *Vj = Vt + j * N;
+#pragma unroll
                 for (int k = 0; k < N; k++) {
                     double t0 = c * Vi[k] + s * Vj[k];
                     double t1 = -s * Vi[k] + c * Vj[k];
