@@ -1,6 +1,7 @@
 // micro-benchmark: issue rate of v_bcnt_u32_b32 / v_xor / v_add on gfx950
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 template <int MODE>
 __global__ __launch_bounds__(256) void k(uint32_t* out, uint32_t seed, int iters, const uint32_t* __restrict__ u) {
     uint32_t a[8], acc[8];
@@ -15,17 +16,24 @@ __global__ __launch_bounds__(256) void k(uint32_t* out, uint32_t seed, int iters
             if (MODE == 4) acc[i] = (u[(it & 7) * 8 + i] ^ a[i]) + acc[i];    // xor with SGPR operand + add
             if (MODE == 5) acc[i] = __popc(u[(it & 7) * 8 + i] ^ a[i]) + acc[i]; // xor(SGPR) + bcnt(acc)
             if (MODE == 6) acc[i] = min(a[i], acc[i]) + 1;                // min + add
+            if (MODE == 7) acc[i] = __builtin_rotateleft32(acc[i], 16) + a[i];   // alignbit + add
+            if (MODE == 8) acc[i] = min(max(a[i], acc[i]), max(min(a[i], acc[i]), a[(i + 1) & 7])) + 1;   // med3 + add
+            if (MODE == 9) acc[i] = __umul24(acc[i], 0x204081u) + a[i];   // mul_u24 + add (or mad_u24)
+            if (MODE == 10) acc[i] = (acc[i] << 3) + a[i];                 // lshl_add
+            if (MODE == 11) acc[i] = ((acc[i] >> 4) & 0xF) + a[i];         // bfe + add
+            if (MODE == 12) acc[i] = (acc[i] & a[i]) + 1;                  // and + add
         }
     }
     uint32_t s = 0;
     for (int i = 0; i < 8; i++) s += acc[i];
     out[blockIdx.x * 256 + threadIdx.x] = s;
 }
+static int g_blocks = 256 * 8;
 template <int MODE>
 void run(const char* name, int ops) {
     uint32_t* d;
     hipMalloc(&d, 256 * 8 * 256 * 4 * 4);
-    const int blocks = 256 * 8, iters = 4096;
+    const int blocks = g_blocks, iters = 4096;
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(256), 0, 0, d, 12345u, iters, (const uint32_t*)d);
@@ -39,7 +47,9 @@ void run(const char* name, int ops) {
     printf("%-12s %.3f ms  %.2f T lane-instr/s\n", name, ms, laneops / (ms * 1e-3) / 1e12);
     hipFree(d);
 }
-int main() {
+int main(int argc, char** argv) {
+    if (argc > 1) g_blocks = atoi(argv[1]);
+    printf("blocks %d (%.2f waves/SIMD)\n", g_blocks, g_blocks / 256.0);
     run<0>("xor+bcnt", 2);
     run<1>("xor+add", 2);
     run<2>("bcnt", 1);
@@ -47,5 +57,11 @@ int main() {
     run<4>("xorS+add", 2);
     run<5>("xorS+bcnt", 2);
     run<6>("min+add", 2);
+    run<7>("alignbit+add", 2);
+    run<8>("med3+add", 2);
+    run<9>("mul24+add", 2);
+    run<10>("lshl_add", 1);
+    run<11>("bfe+add", 2);
+    run<12>("and+add", 2);
     return 0;
 }

@@ -142,7 +142,7 @@ static int ctx_init(vo_ctx* c) {
     ALLOC(c, c->d_kp, (size_t)F * kc * sizeof(vo_keypoint));
     ALLOC(c, c->d_kplvl, (size_t)F * kc * 4);
     ALLOC(c, c->d_desc, (size_t)F * kc * 32);
-    ALLOC(c, c->d_match, (size_t)CP * 8 * kc * sizeof(uint2));   // MATCH_SPLIT segments
+    ALLOC(c, c->d_match, (size_t)CP * vo_match_segments(kc) * kc * sizeof(uint2));
     ALLOC(c, c->d_raw, (size_t)kc * sizeof(int4));
     ALLOC(c, c->d_nmatch, (size_t)MP * 4);
     ALLOC(c, c->d_pair_status, (size_t)MP * 4);

@@ -150,6 +150,7 @@ int vo_fail(vo_ctx* c, int code, const std::string& msg);
 int vo_build_geometry(vo_ctx* c, int w, int h);
 int vo_launch_detect(vo_ctx* c, const FrameSrc& src, int F, hipStream_t st);
 // match.hip
+int vo_match_segments(int kp_cap);   // train-set segments per pair (rows of d_match)
 int vo_launch_match_impl(vo_ctx* c, int P, int nA, double ratio, int pair0, int4* raw_out, hipStream_t st);
 // pose.hip
 struct PoseK { double fx, fy, cx, cy; };

@@ -5,79 +5,190 @@
 // BFMatcher(NORM_HAMMING) semantics: per query the two smallest
 // (distance, trainIdx) in lexicographic order.
 //
-// k_match: one lane owns one query descriptor (8 dwords in VGPRs); the train descriptors
-// are wave-uniform, so they stream through scalar loads (SGPR operands of v_xor).  Per
-// (query, train): 8 v_xor_b32 + 8 accumulating v_bcnt_u32_b32 + 3 integer ops on the
-// packed key (distance << 16 | trainIdx), whose unsigned order IS the lexicographic
-// (distance, trainIdx) order: best = min(key, best); second = med3(key, best, second).
-// The train set is split into MATCH_SPLIT segments to fill the chip; k_ratio merges the
-// segments, applies the ratio test in Python-double arithmetic and compacts the survivors
-// in ascending query order.  Integer ALU bound: 19 lane-ops per distance.
+// k_match computes the distance matrix on the matrix cores.  With train bits a in {0,1} and query
+// bits b recoded as (1 - 2b) in {+1,-1}, one 32x32 tile of Hamming distances is
+//     D[t][q] = |b_q| + sum_k a_tk (1 - 2 b_qk) = |a_t| + |b_q| - 2 a_t.b_q
+// i.e. 8 x v_mfma_i32_32x32x32_i8 (K = 256).  A wavefront keeps MM_NQ query tiles (B operands,
+// expanded once) in registers; the 4 wavefronts of a workgroup share each 32-train block: every
+// lane loads ONE packed dword, expands its 32 bits to 0/1 bytes (2.4 VALU ops per 4 bits) and
+// stores them to a double-buffered LDS image that all wavefronts read back as MFMA A operands
+// (ds_read_b128, conflict free), so HBM/L2 only ever see packed descriptors.
+// The operand bytes are scaled to 64 (a in {0,64}, b in {+64,-64}), so the MFMA sum is 4096 x the
+// distance term and the low 12 bits of the accumulator are free: it is preloaded with
+// 4096*256 + 0x800 + row, and the MFMA result IS the packed key (biased distance << 12 | biased
+// block-relative trainIdx), whose unsigned order is the lexicographic (distance, trainIdx)
+// order.  The accumulator layout puts one query on a lane and 16 trains in its registers, so
+// the 2-NN scan is 2 VALU ops per distance (v_med3_u32, v_min_u32), issued in the shadow of the
+// next tile's MFMAs.  The running keys are re-based by -32 per block so the preload never
+// changes (at most 64 blocks per segment).  The train set is split into segments (grid.y);
+// k_ratio merges the segments, applies the ratio test in Python-double arithmetic and compacts
+// the survivors in ascending query order.
+#include <algorithm>
+
 #include "vo_internal.h"
 
-#define MATCH_SPLIT 8
-#define MATCH_QPB 512   // queries per 256-thread block: two per lane, so every scalar train load feeds 2x19 VALU ops
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
 
-__device__ __forceinline__ void match_update(const uint32_t (&a)[8], const uint32_t* __restrict__ b, uint32_t j, uint32_t& k1, uint32_t& k2) {
-    uint32_t d = __popc(a[0] ^ b[0]);
-    d += __popc(a[1] ^ b[1]);
-    d += __popc(a[2] ^ b[2]);
-    d += __popc(a[3] ^ b[3]);
-    d += __popc(a[4] ^ b[4]);
-    d += __popc(a[5] ^ b[5]);
-    d += __popc(a[6] ^ b[6]);
-    d += __popc(a[7] ^ b[7]);
-    const uint32_t key = (d << 16) + j;
-    const uint32_t lo = min(key, k1), hi = max(key, k1);
-    k2 = min(k2, hi);
-    k1 = lo;
+#define MATCH_SEG_TRAINS 2016         // trains per segment: 63 blocks of 32 (12-bit block-relative index)
+#define MM_QPB (4 * MM_NQ * 32)      // queries per 256-thread block (MM_NQ 32-query tiles per wavefront)
+#define MM_REGION 528                // LDS bytes per (k-step, half) region: 32 trains x 16 B + 16 B pad
+#define MM_BUF (16 * MM_REGION)
+#define BYTE(d, k) (((d) >> (8 * (k))) & 0xFFu)
+
+// nibble x (0..15) -> dword whose byte i is 64 * bit i of x
+__device__ __forceinline__ uint32_t spread4(uint32_t x) { return (__umul24(x, 0x204081u) << 6) & 0x40404040u; }
+
+// 32 descriptor bits -> two k-steps of 16 bytes (0/64): bits [0,16) and [16,32)
+__device__ __forceinline__ void expand_dword(uint32_t w, v4i& s0, v4i& s1) {
+    const uint32_t lo = w & 0x0F0F0F0Fu, hi = (w >> 4) & 0x0F0F0F0Fu;
+    s0 = v4i{(int)spread4(BYTE(lo, 0)), (int)spread4(BYTE(hi, 0)), (int)spread4(BYTE(lo, 1)), (int)spread4(BYTE(hi, 1))};
+    s1 = v4i{(int)spread4(BYTE(lo, 2)), (int)spread4(BYTE(hi, 2)), (int)spread4(BYTE(lo, 3)), (int)spread4(BYTE(hi, 3))};
 }
 
+__device__ __forceinline__ void key_update(uint32_t key, uint32_t& k1, uint32_t& k2) {
+    // k1 <= k2: the new second-smallest is the median of (key, k1, k2); this form selects v_med3_u32
+    k2 = min(max(key, k1), max(min(key, k1), k2));
+    k1 = min(k1, key);
+}
+
+template <int MM_NQ>
 __global__ __launch_bounds__(256) void k_match(const uint8_t* __restrict__ desc, const int* __restrict__ nkp, int kp_cap, int nA,
-                                               uint2* __restrict__ seg_best) {
+                                               int nseg, uint2* __restrict__ seg_best) {
+    __shared__ __attribute__((aligned(16))) uint8_t abuf[2 * MM_BUF];
     const int p = blockIdx.z, seg = blockIdx.y;
     const int qf = p, tf = nA + p;
     const int nq = nkp[qf], nt = nkp[tf];
-    if (blockIdx.x * MATCH_QPB >= nq) return;
-    const int qa = blockIdx.x * MATCH_QPB + threadIdx.x, qb = qa + 256;
-    uint32_t a[8], c[8];
-    {
-        const uint32_t* qp = reinterpret_cast<const uint32_t*>(desc + ((long)qf * kp_cap + min(qa, nq - 1)) * 32);
-        uint4 lo = *reinterpret_cast<const uint4*>(qp), hi = *reinterpret_cast<const uint4*>(qp + 4);
-        a[0] = lo.x; a[1] = lo.y; a[2] = lo.z; a[3] = lo.w; a[4] = hi.x; a[5] = hi.y; a[6] = hi.z; a[7] = hi.w;
-        qp = reinterpret_cast<const uint32_t*>(desc + ((long)qf * kp_cap + min(qb, nq - 1)) * 32);
-        lo = *reinterpret_cast<const uint4*>(qp); hi = *reinterpret_cast<const uint4*>(qp + 4);
-        c[0] = lo.x; c[1] = lo.y; c[2] = lo.z; c[3] = lo.w; c[4] = hi.x; c[5] = hi.y; c[6] = hi.z; c[7] = hi.w;
+    if ((int)blockIdx.x * MM_QPB >= nq) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 31, h = lane >> 5;
+    const int q0 = blockIdx.x * MM_QPB + wave * (MM_NQ * 32);
+    // query tiles: lane (n, h) holds half h of query q0 + 32u + n, recoded to +1 / -1; k-step s = bits [16s, 16s+16) of the half
+    v4i B[MM_NQ][8];
+    int pc[MM_NQ];
+#pragma unroll
+    for (int u = 0; u < MM_NQ; u++) {
+        const int q = min(q0 + 32 * u + n, nq - 1);
+        const uint4 raw = *reinterpret_cast<const uint4*>(desc + ((long)qf * kp_cap + q) * 32 + 16 * h);
+        expand_dword(raw.x, B[u][0], B[u][1]);
+        expand_dword(raw.y, B[u][2], B[u][3]);
+        expand_dword(raw.z, B[u][4], B[u][5]);
+        expand_dword(raw.w, B[u][6], B[u][7]);
+#pragma unroll
+        for (int s = 0; s < 8; s++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const uint32_t x = (uint32_t)B[u][s][j];
+                B[u][s][j] = (int)((x << 1) | 0x40404040u);   // byte 64 -> 0xC0 (-64), byte 0 -> 0x40 (+64)
+            }
+        const int half = __popc(raw.x) + __popc(raw.y) + __popc(raw.z) + __popc(raw.w);
+        pc[u] = half + __shfl_xor(half, 32);
     }
-    const int per = (nt + MATCH_SPLIT - 1) / MATCH_SPLIT;
+    uint32_t k1[MM_NQ], k2[MM_NQ];
+#pragma unroll
+    for (int u = 0; u < MM_NQ; u++) k1[u] = k2[u] = 0xFFFFFFFFu;
+    const int per = (((nt + nseg - 1) / nseg) + 31) & ~31;   // multiple of 32: only the last segment has a ragged block
     const int t0 = seg * per, t1 = min(t0 + per, nt);
-    const uint32_t* tp = reinterpret_cast<const uint32_t*>(desc + (long)tf * kp_cap * 32);
-    uint32_t ka1 = 0xFFFFFFFFu, ka2 = 0xFFFFFFFFu, kc1 = 0xFFFFFFFFu, kc2 = 0xFFFFFFFFu;
-    int j = t0;
-    for (; j + 4 <= t1; j += 4) {
-        // four wave-uniform train descriptors (scalar loads) in flight per iteration
-        const uint32_t* b = tp + (long)j * 8;
-        uint32_t t[32];
+    const int nblk = t0 < t1 ? (t1 - t0 + 31) >> 5 : 0;
+    if (nblk > 0) {   // uniform over the workgroup
+        // register i of lane (n, h) is train row (i&3) + 8(i>>2) + 4h of the block; the lane-constant 4h is added after the loop
+        v16i cinit;
 #pragma unroll
-        for (int k = 0; k < 32; k++) t[k] = b[k];
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            match_update(a, t + 8 * u, (uint32_t)(j + u), ka1, ka2);
-            match_update(c, t + 8 * u, (uint32_t)(j + u), kc1, kc2);
+        for (int i = 0; i < 16; i++) cinit[i] = 4096 * 256 + 0x800 + (i & 3) + 8 * (i >> 2);
+        // producer role: thread tid owns dword (tid & 7) of train (tid >> 3) of the block:
+        // half = dword >> 2, k-steps 2(dword & 3) and 2(dword & 3) + 1
+        const int pm = tid >> 3, pd = tid & 7;
+        const uint32_t* tp = reinterpret_cast<const uint32_t*>(desc + (long)tf * kp_cap * 32) + pd;
+        uint8_t* wr = abuf + ((4 * (pd & 3) + (pd >> 2)) * MM_REGION + pm * 16);   // region index = 2 * kstep + half
+        const uint8_t* rd = abuf + h * MM_REGION + n * 16;
+        {
+            v4i s0, s1;
+            expand_dword(tp[(long)min(t0 + pm, nt - 1) * 8], s0, s1);
+            *reinterpret_cast<v4i*>(wr) = s0;
+            *reinterpret_cast<v4i*>(wr + 2 * MM_REGION) = s1;
         }
+        uint32_t raw = nblk > 1 ? tp[(long)min(t0 + 32 + pm, nt - 1) * 8] : 0u;
+        __syncthreads();
+        v4i A0[8], A1[8];
+#pragma unroll
+        for (int s = 0; s < 8; s++) A0[s] = *reinterpret_cast<const v4i*>(rd + 2 * s * MM_REGION);
+        // Software pipeline over the tiles (block, u): the 8 MFMAs of a tile are interleaved, two results per
+        // MFMA, with the 2-NN scan of the PREVIOUS tile, so matrix and vector pipes run together inside one
+        // wavefront.  accP is the previous tile's result; it starts as "all sentinels".
+        v16i accP;
+#pragma unroll
+        for (int i = 0; i < 16; i++) accP[i] = -1;
+        auto block = [&](v4i (&Ac)[8], v4i (&An)[8], int it) {
+            if (it + 1 < nblk) {
+                v4i s0, s1;
+                expand_dword(raw, s0, s1);
+                uint8_t* w2 = wr + ((it + 1) & 1) * MM_BUF;
+                *reinterpret_cast<v4i*>(w2) = s0;
+                *reinterpret_cast<v4i*>(w2 + 2 * MM_REGION) = s1;
+                if (it + 2 < nblk) raw = tp[(long)min(t0 + 32 * it + 64 + pm, nt - 1) * 8];
+            } else if (t0 + 32 * nblk > t1) {
+                // ragged last block: rows at or beyond t1 get +1024 on the distance, which reads as a sentinel
+#pragma unroll
+                for (int i = 0; i < 16; i++)
+                    if (t0 + 32 * it + (i & 3) + 8 * (i >> 2) + 4 * h >= t1) cinit[i] += 4096 * 1024;
+            }
+#pragma unroll
+            for (int u = 0; u < MM_NQ; u++) {
+                if (u == MM_NQ - 1) {
+                    __syncthreads();   // block it+1 is complete in LDS; every wavefront has consumed block it-1's image
+                    if (it + 1 < nblk) {
+                        const uint8_t* r2 = rd + ((it + 1) & 1) * MM_BUF;
+#pragma unroll
+                        for (int s = 0; s < 8; s++) An[s] = *reinterpret_cast<const v4i*>(r2 + 2 * s * MM_REGION);
+                    }
+                }
+                const int up = (u + MM_NQ - 1) % MM_NQ;    // the previous tile's query tile
+                k1[up] -= 32;   // re-base its running keys to the block of accP (the sentinel stays above every real key)
+                k2[up] -= 32;
+                // source order = issue order: one MFMA, then six VALU ops of the previous tile's scan in its shadow
+                v16i acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(Ac[0], B[u][0], cinit, 0, 0, 0);
+                key_update((uint32_t)accP[0], k1[up], k2[up]);
+                key_update((uint32_t)accP[1], k1[up], k2[up]);
+                asm volatile("" : "+v"(k1[up]), "+v"(k2[up]));   // keeps the scan ops here (no sinking past the barrier)
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int s = 1; s < 8; s++) {
+                    acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(Ac[s], B[u][s], acc, 0, 0, 0);
+                    key_update((uint32_t)accP[2 * s], k1[up], k2[up]);
+                    key_update((uint32_t)accP[2 * s + 1], k1[up], k2[up]);
+                    asm volatile("" : "+v"(k1[up]), "+v"(k2[up]));
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                accP = acc;
+            }
+        };
+        for (int it = 0; it < nblk; it += 2) {
+            block(A0, A1, it);
+            if (it + 1 < nblk) block(A1, A0, it + 1);
+        }
+        // drain: the last tile
+        k1[MM_NQ - 1] -= 32;
+        k2[MM_NQ - 1] -= 32;
+#pragma unroll
+        for (int i = 0; i < 16; i++) key_update((uint32_t)accP[i], k1[MM_NQ - 1], k2[MM_NQ - 1]);
     }
-    for (; j < t1; j++) {
-        const uint32_t* b = tp + (long)j * 8;
-        match_update(a, b, (uint32_t)j, ka1, ka2);
-        match_update(c, b, (uint32_t)j, kc1, kc2);
+    uint2* out = seg_best + ((long)p * nseg + seg) * kp_cap;
+    const int jlast = t0 + 32 * (nblk - 1);
+#pragma unroll
+    for (int u = 0; u < MM_NQ; u++) {
+        // undo the biases: distance = (key >> 12) - 256 + |b_q|, trainIdx = jlast + (key & 0xFFF) - 0x800 + 4h
+        const uint32_t x1 = k1[u], x2 = k2[u];
+        const uint32_t a1 = (x1 >> 22) == 0 ? ((((x1 >> 12) + pc[u] - 256) << 16) + (uint32_t)(jlast + (int)(x1 & 0xFFF) - 0x800 + 4 * h)) : 0xFFFFFFFFu;
+        const uint32_t a2 = (x2 >> 22) == 0 ? ((((x2 >> 12) + pc[u] - 256) << 16) + (uint32_t)(jlast + (int)(x2 & 0xFFF) - 0x800 + 4 * h)) : 0xFFFFFFFFu;
+        const uint32_t b1 = __shfl_xor(a1, 32), b2 = __shfl_xor(a2, 32);
+        const uint32_t m1 = min(a1, b1), m2 = min(max(a1, b1), min(a2, b2));
+        const int q = q0 + 32 * u + n;
+        if (h == 0 && q < nq) out[q] = make_uint2(m1, m2);
     }
-    uint2* out = seg_best + ((long)p * MATCH_SPLIT + seg) * kp_cap;
-    if (qa < nq) out[qa] = make_uint2(ka1, ka2);
-    if (qb < nq) out[qb] = make_uint2(kc1, kc2);
 }
 
 // merge segments, ratio test, ordered compaction.  One workgroup per pair.
-__global__ __launch_bounds__(1024) void k_ratio(const uint2* __restrict__ seg_best, const int* __restrict__ nkp, int kp_cap, int nA,
+__global__ __launch_bounds__(1024) void k_ratio(const uint2* __restrict__ seg_best, int nseg, const int* __restrict__ nkp, int kp_cap, int nA,
                                                 const vo_keypoint* __restrict__ kps, double ratio, int pair0,
                                                 int4* __restrict__ mq, float2* __restrict__ q1, float2* __restrict__ q2,
                                                 int* __restrict__ nmatch, int* __restrict__ pair_status, int2* __restrict__ pair_nkp,
@@ -100,9 +211,8 @@ __global__ __launch_bounds__(1024) void k_ratio(const uint2* __restrict__ seg_be
         bool keep = false;
         uint32_t k1 = 0xFFFFFFFFu, k2 = 0xFFFFFFFFu;
         if (q < nq) {
-#pragma unroll
-            for (int s = 0; s < MATCH_SPLIT; s++) {
-                const uint2 v = seg_best[((long)p * MATCH_SPLIT + s) * kp_cap + q];
+            for (int s = 0; s < nseg; s++) {
+                const uint2 v = seg_best[((long)p * nseg + s) * kp_cap + q];
                 uint32_t lo = min(v.x, k1), hi = max(v.x, k1);
                 k2 = min(k2, hi); k1 = lo;
                 lo = min(v.y, k1); hi = max(v.y, k1);
@@ -137,12 +247,16 @@ __global__ __launch_bounds__(1024) void k_ratio(const uint2* __restrict__ seg_be
     if (tid == 0) { nmatch[gp] = s_running; pair_status[gp] = VO_OK; }
 }
 
+// segments of the train set: at least 4 to fill the chip, and no more than MATCH_SEG_TRAINS trains each
+int vo_match_segments(int kp_cap) { return std::max(4, (kp_cap + MATCH_SEG_TRAINS - 1) / MATCH_SEG_TRAINS); }
+
 // pairs of the chunk: query frame p, train frame nA + p (descriptors of the last detect)
 int vo_launch_match_impl(vo_ctx* c, int P, int nA, double ratio, int pair0, int4* raw_out, hipStream_t st) {
     const int kp_cap = c->kp_cap;
-    dim3 grid((kp_cap + MATCH_QPB - 1) / MATCH_QPB, MATCH_SPLIT, P);
-    KT(c, st, VO_K_MATCH, hipLaunchKernelGGL(k_match, grid, dim3(256), 0, st, (const uint8_t*)c->d_desc.p, (const int*)c->d_nkp.p, kp_cap, nA, (uint2*)c->d_match.p));
-    KT(c, st, VO_K_RATIO, hipLaunchKernelGGL(k_ratio, dim3(P), dim3(1024), 0, st, (const uint2*)c->d_match.p, (const int*)c->d_nkp.p, kp_cap, nA,
+    const int nseg = vo_match_segments(kp_cap);
+    KT(c, st, VO_K_MATCH, hipLaunchKernelGGL(k_match<3>, dim3((kp_cap + 383) / 384, nseg, P), dim3(256), 0, st, (const uint8_t*)c->d_desc.p,
+                                             (const int*)c->d_nkp.p, kp_cap, nA, nseg, (uint2*)c->d_match.p));
+    KT(c, st, VO_K_RATIO, hipLaunchKernelGGL(k_ratio, dim3(P), dim3(1024), 0, st, (const uint2*)c->d_match.p, nseg, (const int*)c->d_nkp.p, kp_cap, nA,
                        (const vo_keypoint*)c->d_kp.p, ratio, pair0, (int4*)c->d_mq.p, (float2*)c->d_q1.p, (float2*)c->d_q2.p,
                        (int*)c->d_nmatch.p, (int*)c->d_pair_status.p, (int2*)c->d_pair_nkp.p, (const int*)c->d_frame_status.p, raw_out));
     HIP_TRY(c, hipGetLastError());
