@@ -16,6 +16,7 @@
 // All arithmetic is fp64 (fp32 only where OpenCV casts), compiled with -ffp-contract=off.
 #include <cfloat>
 #include <cmath>
+#include <cstdlib>
 
 #include "vo_internal.h"
 
@@ -495,8 +496,8 @@ __global__ void k_ransac_init(PoseWork* pw, const int* __restrict__ nmatch, cons
     for (int i = 0; i < 9; i++) w.E[i] = 0;
 }
 
-// draw the 5-tuples of iterations [iter, iter+VO_HYP_ROUND) of every active pair
-__global__ void k_ransac_sample(PoseWork* pw, const int* __restrict__ nmatch, int P, int* __restrict__ samples) {
+// draw the 5-tuples of iterations [iter, iter+nh) of every active pair (nh <= VO_HYP_ROUND)
+__global__ void k_ransac_sample(PoseWork* pw, const int* __restrict__ nmatch, int P, int nh, int* __restrict__ samples) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= P) return;
     PoseWork& w = pw[p];
@@ -504,7 +505,7 @@ __global__ void k_ransac_sample(PoseWork* pw, const int* __restrict__ nmatch, in
     const int n = nmatch[p];
     DevRNG rng{w.rng};
     int* sp = samples + (long)p * VO_HYP_ROUND * 5;
-    for (int h = 0; h < VO_HYP_ROUND; h++) {
+    for (int h = 0; h < nh; h++) {
         int idx[5];
         if (n == 5) {
             for (int i = 0; i < 5; i++) idx[i] = i;
@@ -525,13 +526,15 @@ __global__ void k_ransac_sample(PoseWork* pw, const int* __restrict__ nmatch, in
     w.rng = rng.state;
 }
 
-__global__ __launch_bounds__(DK_T) void k_ransac_solve(const PoseWork* __restrict__ pw, const int* __restrict__ nmatch, int P, int kp_cap,
+__global__ __launch_bounds__(DK_T) void k_ransac_solve(const PoseWork* __restrict__ pw, const int* __restrict__ nmatch, int P, int nh, int kp_cap,
                                                        const float2* __restrict__ q1, const float2* __restrict__ q2, NormK nk,
                                                        const int* __restrict__ samples, double* __restrict__ models, int* __restrict__ nmodels) {
-    const int p = blockIdx.y, h = blockIdx.x * DK_T + threadIdx.x;
+    // nh (a power of two <= DK_T) hypotheses per pair: a wavefront serves DK_T / nh pairs
+    const int g = blockIdx.x * DK_T + threadIdx.x;
+    const int p = g / nh, h = g % nh;
+    if (p >= P) return;
     const PoseWork& w = pw[p];
     if (w.done) return;
-    if (h >= VO_HYP_ROUND) return;
     const long ho = (long)p * VO_HYP_ROUND + h;
     if (w.iter + h >= w.niters) { nmodels[ho] = 0; return; }   // beyond the current budget: never consumed
     const int* sp = samples + ho * 5;
@@ -549,11 +552,11 @@ __global__ __launch_bounds__(DK_T) void k_ransac_solve(const PoseWork* __restric
 }
 
 // one wavefront per (pair, hypothesis): inlier count of each of its models
-__global__ __launch_bounds__(256) void k_ransac_score(const PoseWork* __restrict__ pw, const int* __restrict__ nmatch, int P, int kp_cap,
+__global__ __launch_bounds__(256) void k_ransac_score(const PoseWork* __restrict__ pw, const int* __restrict__ nmatch, int P, int nh, int kp_cap,
                                                       const float2* __restrict__ q1, const float2* __restrict__ q2, NormK nk, float thr2,
                                                       const double* __restrict__ models, const int* __restrict__ nmodels, int* __restrict__ counts) {
     const int p = blockIdx.y, h = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (pw[p].done || h >= VO_HYP_ROUND) return;
+    if (pw[p].done || h >= nh) return;
     const long ho = (long)p * VO_HYP_ROUND + h;
     const int nm = nmodels[ho];
     if (nm <= 0) return;
@@ -577,7 +580,7 @@ __global__ __launch_bounds__(256) void k_ransac_score(const PoseWork* __restrict
 }
 
 // sequential semantics of RANSACPointSetRegistrator::run over this round's hypotheses
-__global__ void k_ransac_scan(PoseWork* pw, const int* __restrict__ nmatch, int P, double prob, const double* __restrict__ models,
+__global__ void k_ransac_scan(PoseWork* pw, const int* __restrict__ nmatch, int P, int nh, double prob, const double* __restrict__ models,
                               const int* __restrict__ nmodels, const int* __restrict__ counts, int* __restrict__ active) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= P) return;
@@ -594,7 +597,7 @@ __global__ void k_ransac_scan(PoseWork* pw, const int* __restrict__ nmatch, int 
         return;
     }
     int h = 0;
-    for (; h < VO_HYP_ROUND && iter < niters; h++, iter++) {
+    for (; h < nh && iter < niters; h++, iter++) {
         const long ho = (long)p * VO_HYP_ROUND + h;
         const int nm = nmodels[ho];
         for (int m = 0; m < nm; m++) {
@@ -685,14 +688,15 @@ __device__ void triangulate_one(const double* P1, const double* P2, double x1, d
 }
 
 // cheirality vote: one lane per (pair, match, candidate pose)
-__global__ __launch_bounds__(256) void k_cheirality(const PoseWork* __restrict__ pw, const int* __restrict__ nmatch, int kp_cap,
+__global__ __launch_bounds__(64) void k_cheirality(const PoseWork* __restrict__ pw, const int* __restrict__ nmatch, int kp_cap,
                                                     const float2* __restrict__ q1, const float2* __restrict__ q2, NormK nk, double dist_thresh,
                                                     int* __restrict__ vote) {
     const int p = blockIdx.y, c = blockIdx.z;
     const PoseWork& w = pw[p];
     if (w.status != VO_OK) return;
     const int n = nmatch[p];
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (blockIdx.x * 64 >= n) return;
     int m = 0;
     if (i < n) {
         const double* Rc = (c & 1) ? w.R2 : w.R1;
@@ -773,13 +777,18 @@ int vo_launch_ransac(vo_ctx* c, int P, const double K[9], double prob, double th
     int* active = (int*)c->d_misc.p;
     const int pb = (P + 63) / 64;
     hipLaunchKernelGGL(k_ransac_init, dim3(pb), dim3(64), 0, st, pw, nmatch, (const int*)c->d_pair_status.p, P, max_iters);
-    const int max_rounds = (std::max(max_iters, 1) + VO_HYP_ROUND - 1) / VO_HYP_ROUND;
-    for (int round = 0; round < max_rounds; round++) {
+    // The first round is small: with the usual inlier ratios the adaptive iteration count drops below it
+    // after the first good model, and a small round packs several pairs into one solver wavefront.
+    static const int first_round = getenv("VO_RANSAC_FIRST") ? atoi(getenv("VO_RANSAC_FIRST")) : 16;
+    int iters_done = 0;
+    for (int round = 0; iters_done < std::max(max_iters, 1); round++) {
+        const int nh = round == 0 ? first_round : VO_HYP_ROUND;
         HIP_TRY(c, hipMemsetAsync(active, 0, sizeof(int), st));
-        hipLaunchKernelGGL(k_ransac_sample, dim3(pb), dim3(64), 0, st, pw, nmatch, P, samples);
-        hipLaunchKernelGGL(k_ransac_solve, dim3(VO_HYP_ROUND / DK_T, P), dim3(DK_T), 0, st, pw, nmatch, P, kp_cap, q1, q2, nk, samples, models, nmodels);
-        hipLaunchKernelGGL(k_ransac_score, dim3(VO_HYP_ROUND / 4, P), dim3(256), 0, st, pw, nmatch, P, kp_cap, q1, q2, nk, thr2, models, nmodels, counts);
-        hipLaunchKernelGGL(k_ransac_scan, dim3(pb), dim3(64), 0, st, pw, nmatch, P, prob, models, nmodels, counts, active);
+        hipLaunchKernelGGL(k_ransac_sample, dim3(pb), dim3(64), 0, st, pw, nmatch, P, nh, samples);
+        hipLaunchKernelGGL(k_ransac_solve, dim3((P * nh + DK_T - 1) / DK_T), dim3(DK_T), 0, st, pw, nmatch, P, nh, kp_cap, q1, q2, nk, samples, models, nmodels);
+        hipLaunchKernelGGL(k_ransac_score, dim3((nh + 3) / 4, P), dim3(256), 0, st, pw, nmatch, P, nh, kp_cap, q1, q2, nk, thr2, models, nmodels, counts);
+        hipLaunchKernelGGL(k_ransac_scan, dim3(pb), dim3(64), 0, st, pw, nmatch, P, nh, prob, models, nmodels, counts, active);
+        iters_done += nh;
         int h_active = 0;
         HIP_TRY(c, hipMemcpyAsync(&h_active, active, sizeof(int), hipMemcpyDeviceToHost, st));
         HIP_TRY(c, hipStreamSynchronize(st));
@@ -798,7 +807,7 @@ int vo_launch_recover(vo_ctx* c, int P, const double K[9], double dist_thresh, h
     int* vote = (int*)c->d_vote.p;
     const int pb = (P + 63) / 64;
     hipLaunchKernelGGL(k_decompose, dim3(pb), dim3(64), 0, st, pw, P, vote);
-    hipLaunchKernelGGL(k_cheirality, dim3((kp_cap + 255) / 256, P, 4), dim3(256), 0, st, pw, (const int*)c->d_nmatch.p, kp_cap,
+    hipLaunchKernelGGL(k_cheirality, dim3((kp_cap + 63) / 64, P, 4), dim3(64), 0, st, pw, (const int*)c->d_nmatch.p, kp_cap,
                        (const float2*)c->d_q1.p, (const float2*)c->d_q2.p, nk, dist_thresh, vote);
     hipLaunchKernelGGL(k_pose_pick, dim3(pb), dim3(64), 0, st, pw, P, vote);
     HIP_TRY(c, hipGetLastError());
