@@ -34,8 +34,24 @@ ALGO_BYTES_PER_FRAME = {
     "k_harris": 2 * NFEAT * 81,
 }
 HBM_PEAK_GBS = 8000.0
-# matcher: 16 lane-ops (8 xor + 8 popcount) per distance; peak = 256 CU x 4 SIMD x 32 lanes x 2.4 GHz
-VALU_PEAK_TOPS = 256 * 4 * 32 * 2.4e9 / 1e12
+# matcher: one Hamming distance = a 256-long i8 dot product on the matrix cores = 512 ops;
+# dense i8 MFMA peak = 2 x bf16 = 256 CU x 4 SIMD x 2048 ops/clk x 2.4 GHz (MI355X_MICROARCH.md, Matrix cores)
+MFMA_I8_PEAK_TOPS = 256 * 4 * 2048 * 2.4e9 / 1e12
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r1_c_pmc_hbm_traffic.json")
+
+
+def measured_traffic(kernel, frames_per_launch):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE + WRITE_SIZE, KB, separate
+    runs of this script; profiles/r1_c_pmc_hbm_traffic.json), scaled to this run's frames per launch.
+    None when the file or the kernel is missing: bench.py itself never runs the profiler."""
+    try:
+        with open(TRAFFIC_FILE) as f:
+            t = json.load(f)
+        k = t["kernels"][kernel]
+        kb = k["FETCH_SIZE_KB_avg_per_launch"] + k["WRITE_SIZE_KB_avg_per_launch"]
+        return int(kb * 1024 * frames_per_launch / t["meta"]["frames_per_launch"])
+    except Exception:
+        return None
 
 
 def cpu_baseline(imgsA, imgsB, K, budget_s=12.0):
@@ -137,13 +153,19 @@ def main():
         avg_s = hbm[dom]["avg_ms"] * 1e-3
         achieved = bytes_per_launch / avg_s / 1e9
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-                    "bytes_per_launch": int(bytes_per_launch), "avg_launch_ms": hbm[dom]["avg_ms"]}
+                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": measured_traffic(dom, frames_per_launch),
+                    "bytes_per_launch": int(bytes_per_launch), "avg_launch_ms": hbm[dom]["avg_ms"],
+                    "note": "k_fast_tiles streams every pyramid pixel once but is VALU-issue bound (min/max arc tests), see DESIGN.md"}
         if "k_match" in kernels:
             nk = res["n_kp1"][:B].astype(np.float64) * res["n_kp2"][:B].astype(np.float64)
-            ops = float(nk.sum()) * 16.0
-            roofline["matcher"] = {"bound": "valu-int", "achieved_Tlaneops": round(ops / (kernels["k_match"]["ms_total"] * 1e-3) / 1e12, 3),
-                                   "peak_Tlaneops": round(VALU_PEAK_TOPS, 2)}
+            ops = float(nk.sum()) * 512.0
+            a = ops / (kernels["k_match"]["ms_total"] * 1e-3) / 1e12
+            roofline["matcher"] = {"bound": "mfma", "kernel": "k_match", "achieved": round(a, 1), "peak": round(MFMA_I8_PEAK_TOPS, 1),
+                                   "unit": "TOP/s (i8)", "frac": round(a / MFMA_I8_PEAK_TOPS, 4), "avg_launch_ms": kernels["k_match"]["avg_ms"],
+                                   # the same work in the north-star's terms: 8 xor + 8 popcount lane-ops per distance;
+                                   # tools/ubench measures 36.1 T lane-ops/s for the xor+v_bcnt pair on this chip (v_bcnt is half rate)
+                                   "equiv_xor_popcount_Tlaneops": round(float(nk.sum()) * 16.0 / (kernels["k_match"]["ms_total"] * 1e-3) / 1e12, 2),
+                                   "valu_xor_popcount_ceiling_Tlaneops": 36.1}
 
     cpu = None
     if rank == 0 and not args.no_cpu:
