@@ -79,6 +79,8 @@ def main():
     ap.add_argument("--chunk", type=int, default=64, help="pairs per detect/match launch wave")
     ap.add_argument("--workers", type=int, default=0, help="host processes for input generation (0 = auto; use 1 under rocprofv3)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--sequence", action="store_true",
+                    help="extra diagnostic: also time vo_sequence_run_device on the A frames taken as one sequence (each frame extracted once)")
     args = ap.parse_args()
 
     import torch
@@ -167,6 +169,22 @@ def main():
                                    "equiv_xor_popcount_Tlaneops": round(float(nk.sum()) * 16.0 / (kernels["k_match"]["ms_total"] * 1e-3) / 1e12, 2),
                                    "valu_xor_popcount_ceiling_Tlaneops": 36.1}
 
+    seq = None
+    if rank == 0 and args.sequence:
+        # same kernels on one B-frame sequence A_k,B_k,A_k,B_k,... (blocks of 16 frames per distinct pair), so that
+        # consecutive frames are related views; every frame is extracted once per chunk
+        f = np.arange(B)
+        k = (f // 16) % nd
+        dS = torch.where(torch.from_numpy((f % 2 == 0)).cuda()[:, None, None], dA[torch.from_numpy(k).cuda()], dB[torch.from_numpy(k).cuda()]).contiguous()
+        ctx.sequence_run_device(dS.data_ptr(), B, W_IMG, H_IMG, W_IMG, K)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            r2 = ctx.sequence_run_device(dS.data_ptr(), B, W_IMG, H_IMG, W_IMG, K)
+        torch.cuda.synchronize()
+        seq = {"frame_pairs_per_sec": round((B - 1) * args.steps / (time.perf_counter() - t1), 2), "pairs_ok": int((r2["status"] == 0).sum()),
+               "pairs_total": B - 1, "note": "consecutive-pair mode (SURVEY 8(f) N3): B frames, B-1 pairs, each frame extracted once per chunk"}
+
     cpu = None
     if rank == 0 and not args.no_cpu:
         cpu = cpu_baseline(imgsA, imgsB, K)
@@ -181,7 +199,7 @@ def main():
             "config": {"workload": "configs[2]: batch of synthetic 1241x376 pairs (configs[1] generator, seeds 0..), 3000 ORB features, 8 levels",
                        "pairs_per_gpu": B, "distinct_pairs_per_gpu": nd, "global_pairs": world * B, "chunk_pairs": min(args.chunk, B), "parallelism": "pairs sharded over ranks, no collective",
                        "pairs_ok": ok, "pairs_total": int(len(res))},
-            "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels,
+            "roofline": roofline, "cpu_baseline": cpu, "sequence_mode": seq, "kernels": kernels,
         }
         print(json.dumps(out))
     if world > 1:

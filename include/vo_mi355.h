@@ -117,6 +117,18 @@ int vo_pairs_run_device(vo_ctx* ctx, const uint8_t* imgsA_dev, const uint8_t* im
 int vo_pairs_run(vo_ctx* ctx, const uint8_t* imgsA, const uint8_t* imgsB, int B,
                  int w, int h, int stride, const double K[9], double ratio, vo_pair_result* out);
 
+/* A sequence: F consecutive frames [F][h][stride] (device memory), pair i = (frame i, frame i+1)
+ * for i in [0, F-1), i.e. the (prev, cur) pairs the per-frame loop of vo.py:48-190 hands to
+ * get_matches / get_pose.  Each frame is extracted once per chunk instead of twice
+ * (libs/vo_utils.py:94-95 re-extracts the previous frame on every call); the results are
+ * identical to vo_pairs_run_device on the same pairs.  out: HOST array [F-1]. */
+int vo_sequence_run_device(vo_ctx* ctx, const uint8_t* imgs_dev, int F, int w, int h, int stride,
+                           const double K[9], double ratio, vo_pair_result* out_host, void* stream);
+
+/* Same with host images (adds the H2D copy). */
+int vo_sequence_run(vo_ctx* ctx, const uint8_t* imgs, int F, int w, int h, int stride,
+                    const double K[9], double ratio, vo_pair_result* out);
+
 /* Stage read-back for parity tests: copies an internal device buffer of the last
  * vo_orb_detect_compute / vo_pairs_run* chunk to host.  `what`: see VO_DBG_*.
  * Returns the number of bytes the buffer holds (copying at most `bytes`). */

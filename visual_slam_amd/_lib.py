@@ -34,7 +34,7 @@ PAIR_DTYPE = np.dtype([("T", "<f8", (4, 4)), ("n_kp1", "<i4"), ("n_kp2", "<i4"),
 # every symbol include/vo_mi355.h declares
 EXPORTS = [
     "vo_default_orb_params", "vo_ctx_create", "vo_ctx_destroy", "vo_last_error", "vo_orb_detect_compute", "vo_match_knn2_ratio",
-    "vo_match_knn2", "vo_find_essential_ransac", "vo_recover_pose", "vo_triangulate", "vo_pairs_run_device", "vo_pairs_run",
+    "vo_match_knn2", "vo_find_essential_ransac", "vo_recover_pose", "vo_triangulate", "vo_pairs_run_device", "vo_pairs_run", "vo_sequence_run_device", "vo_sequence_run",
     "vo_debug_read", "vo_set_debug_stop", "vo_set_kernel_timing", "vo_get_kernel_timing",
 ]
 
@@ -64,6 +64,8 @@ def load():
     lib.vo_triangulate.argtypes = [vp, vp, vp, vp, vp, i, vp]
     lib.vo_pairs_run_device.argtypes = [vp, vp, vp, i, i, i, i, vp, d, vp, vp]
     lib.vo_pairs_run.argtypes = [vp, vp, vp, i, i, i, i, vp, d, vp]
+    lib.vo_sequence_run_device.argtypes = [vp, vp, i, i, i, i, vp, d, vp, vp]
+    lib.vo_sequence_run.argtypes = [vp, vp, i, i, i, i, vp, d, vp]
     lib.vo_debug_read.argtypes = [vp, i, i, i, vp, C.c_long]
     lib.vo_debug_read.restype = C.c_long
     lib.vo_set_debug_stop.argtypes = [vp, i]
@@ -187,6 +189,23 @@ class Context:
         out = np.zeros(B, PAIR_DTYPE)
         self._check(self.lib.vo_pairs_run_device(self.h, C.c_void_p(ptrA), C.c_void_p(ptrB), B, w, h, stride, _ptr(K), float(ratio), _ptr(out),
                                                  C.c_void_p(stream) if stream else None))
+        return out
+
+    def sequence_run(self, imgs, K, ratio=0.45):
+        """imgs: uint8 [F,h,w] consecutive frames (host).  Returns PAIR_DTYPE [F-1]: pair i = (frame i, frame i+1)."""
+        imgs = np.ascontiguousarray(imgs, np.uint8)
+        F, h, w = imgs.shape
+        K = np.ascontiguousarray(K, np.float64)
+        out = np.zeros(max(F - 1, 0), PAIR_DTYPE)
+        self._check(self.lib.vo_sequence_run(self.h, _ptr(imgs), F, w, h, w, _ptr(K), float(ratio), _ptr(out)))
+        return out
+
+    def sequence_run_device(self, ptr, F, w, h, stride, K, ratio=0.45, stream=None):
+        """ptr: device address of [F][h][stride] uint8 consecutive frames."""
+        K = np.ascontiguousarray(K, np.float64)
+        out = np.zeros(max(F - 1, 0), PAIR_DTYPE)
+        self._check(self.lib.vo_sequence_run_device(self.h, C.c_void_p(ptr), F, w, h, stride, _ptr(K), float(ratio), _ptr(out),
+                                                    C.c_void_p(stream) if stream else None))
         return out
 
     # ---- diagnostics

@@ -398,6 +398,25 @@ int vo_triangulate(vo_ctx* c, const double P1[12], const double P2[12], const fl
 }
 
 // -------------------------------------------------------------------- batched pairs
+// pose stage (findEssentialMat + recoverPose) over the Pb pairs matched so far, results to host
+static int pose_stage(vo_ctx* c, int Pb, const double K[9], vo_pair_result* out, hipStream_t st) {
+    c->last_pairs = Pb;
+    kt_begin(c, st, VO_K_RANSAC);
+    int rc = vo_launch_ransac(c, Pb, K, 0.999, 1.0, 1000, st);
+    kt_end(c, st);
+    if (rc != VO_OK) return rc;
+    kt_begin(c, st, VO_K_RECOVER);
+    rc = vo_launch_recover(c, Pb, K, 50.0, st);
+    kt_end(c, st);
+    if (rc != VO_OK) return rc;
+    hipLaunchKernelGGL(k_results, dim3((Pb + 63) / 64), dim3(64), 0, st, (const PoseWork*)c->d_pose.p, (const int*)c->d_nmatch.p,
+                       (const int2*)c->d_pair_nkp.p, Pb, (vo_pair_result*)c->d_result.p);
+    HIP_TRY(c, hipMemcpyAsync(out, c->d_result.p, (size_t)Pb * sizeof(vo_pair_result), hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipStreamSynchronize(st));
+    if (c->timing) kt_collect(c);
+    return VO_OK;
+}
+
 int vo_pairs_run_device(vo_ctx* c, const uint8_t* imgsA, const uint8_t* imgsB, int B, int w, int h, int stride, const double K[9], double ratio,
                         vo_pair_result* out, void* stream) {
     if (!c) return VO_ERR_INVALID;
@@ -423,20 +442,64 @@ int vo_pairs_run_device(vo_ctx* c, const uint8_t* imgsA, const uint8_t* imgsB, i
                 kt_collect(c);
             }
         }
-        c->last_pairs = Pb;
-        kt_begin(c, st, VO_K_RANSAC);
-        rc = vo_launch_ransac(c, Pb, K, 0.999, 1.0, 1000, st);
-        kt_end(c, st);
+        rc = pose_stage(c, Pb, K, out + b0, st);
         if (rc != VO_OK) return rc;
-        kt_begin(c, st, VO_K_RECOVER);
-        rc = vo_launch_recover(c, Pb, K, 50.0, st);
-        kt_end(c, st);
+    }
+    return VO_OK;
+}
+
+// A sequence of F frames: pair i is (frame i, frame i+1), as the loop of vo.py:48-190 visits them.
+// Every frame is extracted once per chunk (the reference extracts each frame twice, libs/vo_utils.py:94-95);
+// consecutive chunks share one frame.  Results are those of vo_pairs_run_device on the same pairs.
+int vo_sequence_run_device(vo_ctx* c, const uint8_t* imgs, int F, int w, int h, int stride, const double K[9], double ratio,
+                           vo_pair_result* out, void* stream) {
+    if (!c) return VO_ERR_INVALID;
+    if (!imgs || !K || !out || F < 0 || stride < w) return vo_fail(c, VO_ERR_INVALID, "vo_sequence_run_device: bad arguments");
+    if (F < 2) return VO_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    int rc = vo_build_geometry(c, w, h);
+    if (rc != VO_OK) return rc;
+    hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+    const long fs = (long)stride * h;
+    const int B = F - 1;
+    // a chunk of Pc pairs needs Pc+1 frames of the 2*chunk_pairs-frame workspace and Pc rows of the match workspace
+    const int cp = std::min(c->chunk_pairs, 2 * c->chunk_pairs - 1);
+    for (int b0 = 0; b0 < B; b0 += c->max_pairs) {
+        const int Pb = std::min(c->max_pairs, B - b0);
+        for (int p0 = 0; p0 < Pb; p0 += cp) {
+            const int Pc = std::min(cp, Pb - p0);
+            const uint8_t* first = imgs + (long)(b0 + p0) * fs;
+            FrameSrc src{first, first, Pc + 1, stride, fs};
+            c->last_src = src; c->last_frames = Pc + 1;
+            rc = vo_launch_detect(c, src, Pc + 1, st);
+            if (rc != VO_OK) return rc;
+            rc = vo_launch_match_impl(c, Pc, 1, ratio, p0, nullptr, st);   // train frame of pair p = frame p + 1
+            if (rc != VO_OK) return rc;
+            if (c->timing) {
+                HIP_TRY(c, hipStreamSynchronize(st));
+                kt_collect(c);
+            }
+        }
+        rc = pose_stage(c, Pb, K, out + b0, st);
         if (rc != VO_OK) return rc;
-        hipLaunchKernelGGL(k_results, dim3((Pb + 63) / 64), dim3(64), 0, st, (const PoseWork*)c->d_pose.p, (const int*)c->d_nmatch.p,
-                           (const int2*)c->d_pair_nkp.p, Pb, (vo_pair_result*)c->d_result.p);
-        HIP_TRY(c, hipMemcpyAsync(out + b0, c->d_result.p, (size_t)Pb * sizeof(vo_pair_result), hipMemcpyDeviceToHost, st));
-        HIP_TRY(c, hipStreamSynchronize(st));
-        if (c->timing) kt_collect(c);
+    }
+    return VO_OK;
+}
+
+int vo_sequence_run(vo_ctx* c, const uint8_t* imgs, int F, int w, int h, int stride, const double K[9], double ratio, vo_pair_result* out) {
+    if (!c) return VO_ERR_INVALID;
+    if (!imgs || F < 0 || stride < w) return vo_fail(c, VO_ERR_INVALID, "vo_sequence_run: bad arguments");
+    if (F < 2) return VO_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    // stage through device memory: up to 2*chunk_pairs frames at a time, consecutive stages share one frame
+    const long fs = (long)w * h;
+    const int cap = (int)std::min<long>(2L * c->chunk_pairs, (long)(c->d_img.bytes / fs));
+    if (cap < 2) return vo_fail(c, VO_ERR_CAPACITY, "vo_sequence_run: staging buffer too small");
+    for (int f0 = 0; f0 < F - 1; f0 += cap - 1) {
+        const int nf = std::min(cap, F - f0);
+        HIP_TRY(c, hipMemcpy2D(c->d_img.p, w, imgs + (long)f0 * stride * h, stride, w, (size_t)h * nf, hipMemcpyHostToDevice));
+        int rc = vo_sequence_run_device(c, (const uint8_t*)c->d_img.p, nf, w, h, w, K, ratio, out + f0, nullptr);
+        if (rc != VO_OK) return rc;
     }
     return VO_OK;
 }

@@ -840,7 +840,7 @@ __device__ __forceinline__ int comp4(const int4& v, int j) { return j == 0 ? v.x
 // Tile = 64 x VO_BLUR_TH outputs.  Source window = (TH+6) rows x 72 bytes from the dword boundary
 // x0-4.  Row pass: one lane makes 4 adjacent outputs from 3 LDS dwords (10 bytes -> float by
 // v_cvt_f32_ubyteN) and stores a float4; column pass: one lane makes 4 adjacent outputs from 7
-// float4 rows and stores one dword.  The multiply/add order is sepFilter2D's (see oracle).
+// float4 rows and stores one dword.  The multiply/add order is sepFilter2D's.
 __global__ __launch_bounds__(256) void k_blur(const Geom* __restrict__ g, FrameSrc src, const uint8_t* __restrict__ pyr,
                                               uint8_t* __restrict__ blur, const TileDesc* __restrict__ btiles, BlurK bk) {
     __shared__ __attribute__((aligned(16))) uint8_t sp[BL_ROWS * BL_SP];
@@ -962,7 +962,7 @@ __global__ __launch_bounds__(256) void k_blur(const Geom* __restrict__ g, FrameS
 
 // ------------------------------------------------------------------ rBRIEF-256, one wavefront per keypoint
 // A block takes 64 keypoints: first one lane per keypoint evaluates cos/sin (double precision,
-// rounded to float, as the oracle) so the trigonometry is not repeated by all 64 lanes of the
+// rounded to float, as cv2 does) so the trigonometry is not repeated by all 64 lanes of the
 // describing wave; then each of the 4 waves describes 16 keypoints, 4 test pairs per lane.
 #define RB_KPB 64
 __global__ __launch_bounds__(256) void k_rbrief(const Geom* __restrict__ g, const uint8_t* __restrict__ blur, const signed char* __restrict__ pat_g,
