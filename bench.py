@@ -78,6 +78,8 @@ def main():
     ap.add_argument("--distinct", type=int, default=256, help="distinct seeded pairs generated per GPU (tiled up to --pairs)")
     ap.add_argument("--chunk", type=int, default=64, help="pairs per detect/match launch wave")
     ap.add_argument("--workers", type=int, default=0, help="host processes for input generation (0 = auto; use 1 under rocprofv3)")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="contexts (one HIP stream and workspace each) driven by one host thread each; the batch is split between them")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--sequence", action="store_true",
                     help="extra diagnostic: also time vo_sequence_run_device on the A frames taken as one sequence (each frame extracted once)")
@@ -109,12 +111,24 @@ def main():
     K = synth.K_KITTI02
     dA = torch.from_numpy(imgsA).cuda()
     dB = torch.from_numpy(imgsB).cuda()
-    ctx = _lib.Context(max_w=W_IMG, max_h=H_IMG, chunk_pairs=min(args.chunk, B), max_pairs=B, device=local_rank)
+    S = max(1, min(args.streams, B))
+    bounds = [parallel.shard_range(B, i, S) for i in range(S)]
+    ctxs = [_lib.Context(max_w=W_IMG, max_h=H_IMG, chunk_pairs=min(args.chunk, hi - lo), max_pairs=hi - lo, device=local_rank) for lo, hi in bounds]
+    ctx = ctxs[0]
+    fsz = W_IMG * H_IMG
+    pool = None
+    if S > 1:
+        from concurrent.futures import ThreadPoolExecutor
+        pool = ThreadPoolExecutor(S)
+
+    def run_part(i):
+        lo, hi = bounds[i]
+        return ctxs[i].pairs_run_device(dA.data_ptr() + lo * fsz, dB.data_ptr() + lo * fsz, hi - lo, W_IMG, H_IMG, W_IMG, K)
 
     def step():
-        # this rank's shard of the job, then (N > 1) the only collective of the path: an RCCL
-        # all_gather of the 152-byte per-pair result records
-        local = ctx.pairs_run_device(dA.data_ptr(), dB.data_ptr(), B, W_IMG, H_IMG, W_IMG, K)
+        # this rank's shard of the job (split over S contexts/streams; ctypes calls release the GIL), then (N > 1)
+        # the only collective of the path: an RCCL all_gather of the 152-byte per-pair result records
+        local = np.concatenate(list(pool.map(run_part, range(S)))) if pool else run_part(0)
         return parallel.gather_pair_results(local, world * B) if world > 1 else local
 
     def barrier():
@@ -140,10 +154,10 @@ def main():
     kernels = {}
     if rank == 0:
         ctx.set_kernel_timing(True)
-        step()
+        run_part(0)
         kt = ctx.kernel_timing()
         ctx.set_kernel_timing(False)
-        frames_per_launch = 2 * min(args.chunk, B)
+        frames_per_launch = 2 * min(args.chunk, bounds[0][1] - bounds[0][0])
         for name, (ms, n) in kt.items():
             if n:
                 kernels[name] = {"ms_total": round(ms, 4), "launches": n, "avg_ms": round(ms / n, 5)}
@@ -159,7 +173,8 @@ def main():
                     "bytes_per_launch": int(bytes_per_launch), "avg_launch_ms": hbm[dom]["avg_ms"],
                     "note": "k_fast_tiles streams every pyramid pixel once but is VALU-issue bound (min/max arc tests), see DESIGN.md"}
         if "k_match" in kernels:
-            nk = res["n_kp1"][:B].astype(np.float64) * res["n_kp2"][:B].astype(np.float64)
+            nb0 = bounds[0][1] - bounds[0][0]
+            nk = res["n_kp1"][:nb0].astype(np.float64) * res["n_kp2"][:nb0].astype(np.float64)
             ops = float(nk.sum()) * 512.0
             a = ops / (kernels["k_match"]["ms_total"] * 1e-3) / 1e12
             roofline["matcher"] = {"bound": "mfma", "kernel": "k_match", "achieved": round(a, 1), "peak": round(MFMA_I8_PEAK_TOPS, 1),
@@ -197,7 +212,7 @@ def main():
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8/int32 detect+match, f64 pose", "data": "synthetic",
             "config": {"workload": "configs[2]: batch of synthetic 1241x376 pairs (configs[1] generator, seeds 0..), 3000 ORB features, 8 levels",
-                       "pairs_per_gpu": B, "distinct_pairs_per_gpu": nd, "global_pairs": world * B, "chunk_pairs": min(args.chunk, B), "parallelism": "pairs sharded over ranks, no collective",
+                       "pairs_per_gpu": B, "distinct_pairs_per_gpu": nd, "global_pairs": world * B, "chunk_pairs": min(args.chunk, B), "streams_per_gpu": S, "parallelism": "pairs sharded over ranks, no collective",
                        "pairs_ok": ok, "pairs_total": int(len(res))},
             "roofline": roofline, "cpu_baseline": cpu, "sequence_mode": seq, "kernels": kernels,
         }

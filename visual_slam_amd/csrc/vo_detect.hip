@@ -960,19 +960,39 @@ __global__ __launch_bounds__(256) void k_blur(const Geom* __restrict__ g, FrameS
     }
 }
 
+// work item of block b in a grid padded to a multiple of 8 blocks: XCD (b % 8) gets items [(b%8)*G/8, (b%8+1)*G/8)
+__device__ __forceinline__ int xcd_contiguous(int b, int grid) { return (b & 7) * (grid >> 3) + (b >> 3); }
+static inline int pad8(int n) { return (n + 7) & ~7; }
+
 // ------------------------------------------------------------------ rBRIEF-256, one wavefront per keypoint
 // A block takes 64 keypoints: first one lane per keypoint evaluates cos/sin (double precision,
 // rounded to float, as cv2 does) so the trigonometry is not repeated by all 64 lanes of the
 // describing wave; then each of the 4 waves describes 16 keypoints, 4 test pairs per lane.
+// The rotated pattern reaches at most 19 px from the keypoint, so the wavefront first copies the
+// 39-row patch to LDS with row-coalesced dword loads (44 B per row from a 4-byte boundary: ~40
+// cache lines per keypoint instead of ~35 per gather instruction) and samples it there; the next
+// keypoint's patch is loaded into registers while the current one is sampled.
 #define RB_KPB 64
+#define RB_R 19                       // sampling reach: |(x,y)| <= sqrt(13^2 + 13^2) = 18.4, rounded
+#define RB_ROWS (2 * RB_R + 1)        // 39
+#define RB_DW 11                      // dwords per patch row (39 B + up to 3 B of alignment slack)
+#define RB_PITCH 48
+#define RB_LOADS ((RB_ROWS * RB_DW + 63) / 64)   // 7 dwords per lane
 __global__ __launch_bounds__(256) void k_rbrief(const Geom* __restrict__ g, const uint8_t* __restrict__ blur, const signed char* __restrict__ pat_g,
                                                 const int* __restrict__ nkp, const vo_keypoint* __restrict__ kps,
-                                                const uint32_t* __restrict__ kplvl, uint8_t* __restrict__ desc) {
+                                                const uint32_t* __restrict__ kplvl, uint8_t* __restrict__ desc, int nbx, int nframes) {
     __shared__ __attribute__((aligned(16))) signed char pat[1024];
     __shared__ float s_cos[RB_KPB], s_sin[RB_KPB];
-    const int f = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ int s_pitch[VO_MAX_LEVELS];
+    __shared__ long s_ofs[VO_MAX_LEVELS];
+    __shared__ __attribute__((aligned(16))) uint8_t patch[4][RB_ROWS * RB_PITCH];
+    // XCD-aware order: blocks are dealt round-robin over the 8 XCDs, so block b and b+8 share an L2; give each
+    // XCD a contiguous run of (frame, keypoint block) work so that a frame's blurred levels are fetched by one L2
+    const int v = xcd_contiguous(blockIdx.x, gridDim.x);
+    if (v >= nbx * nframes) return;
+    const int f = v / nbx, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = nkp[f];
-    const int k0 = blockIdx.x * RB_KPB;
+    const int k0 = (v - f * nbx) * RB_KPB;
     if (k0 >= n) return;
     reinterpret_cast<int*>(pat)[tid] = reinterpret_cast<const int*>(pat_g)[tid];
     if (tid < RB_KPB && k0 + tid < n) {
@@ -981,6 +1001,14 @@ __global__ __launch_bounds__(256) void k_rbrief(const Geom* __restrict__ g, cons
         s_cos[tid] = (float)cos((double)angle);
         s_sin[tid] = (float)sin((double)angle);
     }
+    if (tid >= 64 && tid < 64 + VO_MAX_LEVELS) {
+        s_pitch[tid - 64] = g->lv[tid - 64].bpitch;
+        s_ofs[tid - 64] = g->lv[tid - 64].blur_ofs;
+    }
+    // the wavefront's 16 keypoints are k0 + wave + 4i: lane i fetches the packed (x, y, level) of the i-th
+    const long fo = (long)f * g->kp_cap;
+    uint32_t my_kl = 0;
+    if (lane < RB_KPB / 4 && k0 + wave + 4 * lane < n) my_kl = kplvl[fo + k0 + wave + 4 * lane];
     __syncthreads();
     // this lane's 4 test pairs (8 pattern points)
     float px0[4], py0[4], px1[4], py1[4];
@@ -989,14 +1017,41 @@ __global__ __launch_bounds__(256) void k_rbrief(const Geom* __restrict__ g, cons
         const signed char* pp = &pat[(lane * 4 + j) * 4];
         px0[j] = (float)pp[0]; py0[j] = (float)pp[1]; px1[j] = (float)pp[2]; py1[j] = (float)pp[3];
     }
-    for (int kk = wave; kk < RB_KPB; kk += 4) {
-        const int idx = k0 + kk;
-        if (idx >= n) break;
-        const long o = (long)f * g->kp_cap + idx;
-        const uint32_t kl = kplvl[o];
-        const LevelGeom& L = g->lv[UNPACK_S(kl)];
-        const int pitch = L.bpitch;
-        const uint8_t* center = blur + (long)f * g->blur_frame + L.blur_ofs + (long)UNPACK_Y(kl) * pitch + UNPACK_X(kl);
+    const uint8_t* fblur = blur + (long)f * g->blur_frame;
+    uint8_t* mypatch = patch[wave];
+    // this lane's share of a patch: dwords i = lane + 64t -> (row i / 11, dword i % 11)
+    int l_src[RB_LOADS], l_dst[RB_LOADS];   // row * 1 (scaled by pitch at use) and LDS byte offset
+#pragma unroll
+    for (int t = 0; t < RB_LOADS; t++) {
+        const int i = lane + 64 * t, r = i / RB_DW, d = i - r * RB_DW;
+        l_src[t] = i < RB_ROWS * RB_DW ? (r << 8 | d) : -1;
+        l_dst[t] = r * RB_PITCH + 4 * d;
+    }
+    uint32_t regs[RB_LOADS];
+    int cur_ax = 0;
+    auto fetch = [&](int i, int& ax) {   // global -> registers for the wavefront's i-th keypoint
+        const uint32_t kl = __shfl(my_kl, i);
+        const int lvl = UNPACK_S(kl) & (VO_MAX_LEVELS - 1);
+        const int pitch = s_pitch[lvl];
+        const int x0 = UNPACK_X(kl) - RB_R;
+        ax = x0 & 3;                                       // patch column 0 sits at byte ax of the LDS rows
+        const uint8_t* base = fblur + s_ofs[lvl] + (long)(UNPACK_Y(kl) - RB_R) * pitch + (x0 - ax);
+#pragma unroll
+        for (int t = 0; t < RB_LOADS; t++)
+            if (l_src[t] >= 0) regs[t] = *reinterpret_cast<const uint32_t*>(base + (long)(l_src[t] >> 8) * pitch + 4 * (l_src[t] & 0xFF));
+    };
+    const int nmine = (min(n - k0, RB_KPB) - wave + 3) >> 2;   // keypoints of this wavefront
+    if (nmine > 0) fetch(0, cur_ax);
+    for (int i = 0; i < nmine; i++) {
+        const int kk = wave + 4 * i;
+        const int ax = cur_ax;
+#pragma unroll
+        for (int t = 0; t < RB_LOADS; t++)
+            if (l_src[t] >= 0) *reinterpret_cast<uint32_t*>(mypatch + l_dst[t]) = regs[t];
+        if (i + 1 < nmine) fetch(i + 1, cur_ax);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const uint8_t* center = mypatch + RB_R * RB_PITCH + RB_R + ax;
         const float a = s_cos[kk], b = s_sin[kk];
         uint32_t nib = 0;
 #pragma unroll
@@ -1005,11 +1060,13 @@ __global__ __launch_bounds__(256) void k_rbrief(const Geom* __restrict__ g, cons
             const float xa1 = px1[j] * a, yb1 = py1[j] * b, xb1 = px1[j] * b, ya1 = py1[j] * a;
             const int ix0 = __float2int_rn(xa0 - yb0), iy0 = __float2int_rn(xb0 + ya0);
             const int ix1 = __float2int_rn(xa1 - yb1), iy1 = __float2int_rn(xb1 + ya1);
-            const int t0 = center[iy0 * pitch + ix0], t1 = center[iy1 * pitch + ix1];
+            const int t0 = center[iy0 * RB_PITCH + ix0], t1 = center[iy1 * RB_PITCH + ix1];
             nib |= (uint32_t)(t0 < t1) << j;
         }
         const uint32_t hi = __shfl_down(nib, 1);
-        if ((lane & 1) == 0) desc[o * 32 + (lane >> 1)] = (uint8_t)(nib | (hi << 4));
+        if ((lane & 1) == 0) desc[(fo + k0 + kk) * 32 + (lane >> 1)] = (uint8_t)(nib | (hi << 4));
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();   // all lanes have sampled before the patch is overwritten
     }
 }
 
@@ -1071,8 +1128,9 @@ int vo_launch_detect(vo_ctx* c, const FrameSrc& src, int F, hipStream_t st) {
     BlurK bk;
     gaussian_kernel7_sigma2(bk);
     KT(c, st, VO_K_BLUR, hipLaunchKernelGGL(k_blur, dim3(g.nbtiles, F), dim3(256), 0, st, dg, src, pyr, blur, (const TileDesc*)c->d_btiles.p, bk));
-    KT(c, st, VO_K_RBRIEF, hipLaunchKernelGGL(k_rbrief, dim3((g.kp_cap + RB_KPB - 1) / RB_KPB, F), dim3(256), 0, st, dg, blur, (const signed char*)c->d_pat.p, (const int*)c->d_nkp.p,
-                       (const vo_keypoint*)c->d_kp.p, (const uint32_t*)c->d_kplvl.p, (uint8_t*)c->d_desc.p));
+    const int rb_nbx = (g.kp_cap + RB_KPB - 1) / RB_KPB;
+    KT(c, st, VO_K_RBRIEF, hipLaunchKernelGGL(k_rbrief, dim3(pad8(rb_nbx * F)), dim3(256), 0, st, dg, blur, (const signed char*)c->d_pat.p, (const int*)c->d_nkp.p,
+                       (const vo_keypoint*)c->d_kp.p, (const uint32_t*)c->d_kplvl.p, (uint8_t*)c->d_desc.p, rb_nbx, F));
     HIP_TRY(c, hipGetLastError());
     return VO_OK;
 }
