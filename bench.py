@@ -80,6 +80,9 @@ def main():
     ap.add_argument("--workers", type=int, default=0, help="host processes for input generation (0 = auto; use 1 under rocprofv3)")
     ap.add_argument("--streams", type=int, default=1,
                     help="contexts (one HIP stream and workspace each) driven by one host thread each; the batch is split between them")
+    ap.add_argument("--ba", action="store_true",
+                    help="extra diagnostic: time the BA residual/Jacobian pass of configs[4] (1000 poses x 200k points x 5 obs, points "
+                         "sharded over ranks, pose blocks all-reduced over RCCL)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--sequence", action="store_true",
                     help="extra diagnostic: also time vo_sequence_run_device on the A frames taken as one sequence (each frame extracted once)")
@@ -200,6 +203,38 @@ def main():
         seq = {"frame_pairs_per_sec": round((B - 1) * args.steps / (time.perf_counter() - t1), 2), "pairs_ok": int((r2["status"] == 0).sum()),
                "pairs_total": B - 1, "note": "consecutive-pair mode (SURVEY 8(f) N3): B frames, B-1 pairs, each frame extracted once per chunk"}
 
+    ba_out = None
+    if args.ba:
+        from visual_slam_amd import ba as BA
+        pr = BA.synth_problem(1000, 200000, 5, seed=0)
+        sh = BA.shard_observations(pr, rank, world)
+        plan = BA.BAPlan(sh["obs_pose"], sh["obs_point"], 1000, 200000, device=local_rank)
+        M = len(sh["obs_pose"])
+        dev = torch.device("cuda", local_rank)
+        t_p = torch.from_numpy(sh["poses"]).to(dev); t_x = torch.from_numpy(sh["points"]).to(dev); t_uv = torch.from_numpy(sh["uv"]).to(dev)
+        o_r = torch.empty((M, 2), dtype=torch.float64, device=dev); o_n = torch.empty(M, dtype=torch.float64, device=dev)
+        o_Hpp = torch.empty((1000, 6, 6), dtype=torch.float64, device=dev); o_bp = torch.empty((1000, 6), dtype=torch.float64, device=dev)
+        o_Hll = torch.empty((200000, 3, 3), dtype=torch.float64, device=dev); o_bl = torch.empty((200000, 3), dtype=torch.float64, device=dev)
+        o_Hpl = torch.empty((M, 6, 3), dtype=torch.float64, device=dev)
+
+        def ba_step():
+            plan.run_device(t_p.data_ptr(), t_x.data_ptr(), t_uv.data_ptr(), pr["K"], o_r.data_ptr(), o_n.data_ptr(), o_Hpp.data_ptr(),
+                            o_bp.data_ptr(), o_Hll.data_ptr(), o_bl.data_ptr(), o_Hpl.data_ptr())
+            return BA.allreduce_pose_blocks(o_Hpp, o_bp)
+
+        for _ in range(3):
+            ba_step()
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(20):
+            ba_step()
+        barrier()
+        ba_dt = parallel.max_over_ranks((time.perf_counter() - t1) / 20)
+        ba_out = {"workload": "configs[4]: 1000 poses x 200000 points x 5 observations, fp64, residuals + Hpp/bp/Hll/bl/Hpl", "ms_per_pass": round(ba_dt * 1e3, 4),
+                  "observations_per_sec": round(1e6 / ba_dt, 1), "rms_residual_px": round(float(torch.sqrt((o_n ** 2).mean())), 4),
+                  "collective": "all_reduce of [1000,42] f64 pose blocks" if world > 1 else "none (1 rank)"}
+        plan.close()
+
     cpu = None
     if rank == 0 and not args.no_cpu:
         cpu = cpu_baseline(imgsA, imgsB, K)
@@ -214,7 +249,7 @@ def main():
             "config": {"workload": "configs[2]: batch of synthetic 1241x376 pairs (configs[1] generator, seeds 0..), 3000 ORB features, 8 levels",
                        "pairs_per_gpu": B, "distinct_pairs_per_gpu": nd, "global_pairs": world * B, "chunk_pairs": min(args.chunk, B), "streams_per_gpu": S, "parallelism": "pairs sharded over ranks, no collective",
                        "pairs_ok": ok, "pairs_total": int(len(res))},
-            "roofline": roofline, "cpu_baseline": cpu, "sequence_mode": seq, "kernels": kernels,
+            "roofline": roofline, "cpu_baseline": cpu, "sequence_mode": seq, "ba_pass": ba_out, "kernels": kernels,
         }
         print(json.dumps(out))
     if world > 1:

@@ -129,6 +129,29 @@ int vo_sequence_run_device(vo_ctx* ctx, const uint8_t* imgs_dev, int F, int w, i
 int vo_sequence_run(vo_ctx* ctx, const uint8_t* imgs, int F, int w, int h, int stride,
                     const double K[9], double ratio, vo_pair_result* out);
 
+/* ---- Bundle-adjustment residual / Jacobian pass (BASELINE.json configs[4]).
+ * Replaces the finite-difference evaluation of VisualOdometry.bundle_adjustment_residuals
+ * (libs/vo_utils.py:218-245 -> calc_reprojection_error :184-216 -> cv2.projectPoints, D = 0) that
+ * scipy.optimize.least_squares performs at vo.py:118, generalised to P poses.
+ * A plan holds the observation structure (static over solver iterations): observation o sees
+ * point obs_point[o] from pose obs_pose[o].  poses [P][6] = (rvec, tvec) world->camera, points
+ * [N][3], uv [M][2], all float64.  Outputs (any may be NULL): r [M][2] = projected - observed,
+ * norm [M] = the reference's scalar residual, Hpp [P][6][6] = sum Jp^T Jp, bp [P][6] = sum Jp^T r,
+ * Hll [N][3][3], bl [N][3], Hpl [M][6][3] = Jp^T Jl.  Reductions are atomic-free and
+ * deterministic.  With observations sharded over GPUs, Hpp/bp are the rank's partial sums: one
+ * all-reduce of the [P][42] block completes them (visual_slam_amd/ba.py). */
+typedef struct vo_ba_plan vo_ba_plan;
+int vo_ba_plan_create(int device, int n_poses, int n_points, int n_obs, const int32_t* obs_pose,
+                      const int32_t* obs_point, vo_ba_plan** out);
+void vo_ba_plan_destroy(vo_ba_plan* plan);
+/* device pointers; stream: hipStream_t or NULL (NULL = the plan's stream, synchronised on return) */
+int vo_ba_pass_device(vo_ba_plan* plan, const double* poses_dev, const double* points_dev, const double* uv_dev,
+                      const double K[9], double* r_dev, double* norm_dev, double* Hpp_dev, double* bp_dev,
+                      double* Hll_dev, double* bl_dev, double* Hpl_dev, void* stream);
+/* host pointers (adds the copies) */
+int vo_ba_pass(vo_ba_plan* plan, const double* poses, const double* points, const double* uv, const double K[9],
+               double* r, double* norm, double* Hpp, double* bp, double* Hll, double* bl, double* Hpl);
+
 /* Stage read-back for parity tests: copies an internal device buffer of the last
  * vo_orb_detect_compute / vo_pairs_run* chunk to host.  `what`: see VO_DBG_*.
  * Returns the number of bytes the buffer holds (copying at most `bytes`). */

