@@ -57,3 +57,22 @@ def test_trajectory_on_kitti02_follows_ground_truth():
     est_dir = out["estimated_path"][-1] / np.linalg.norm(out["estimated_path"][-1])
     gt_dir = out["gt_path"][-1] / np.linalg.norm(out["gt_path"][-1])
     assert float(est_dir @ gt_dir) > 0.99
+
+
+def test_loader_feeds_sequence_run(kitti02, K02):
+    """Frames decoded by the loader, uploaded on its side stream, run chunk by chunk == one sequence_run."""
+    import torch
+    from visual_slam_amd import _lib, loader
+    paths = loader.load_image_paths(os.path.join(GOLDEN, "kitti02"))
+    imgs = np.stack(kitti02)
+    F, h, w = imgs.shape
+    ctx = _lib.Context(max_w=w, max_h=h, chunk_pairs=2, max_pairs=F - 1)
+    ref = ctx.sequence_run(imgs, K02)
+    got = []
+    for d in loader.FrameLoader(paths, chunk=3, overlap=1, workers=2, device=0):
+        assert d.is_cuda and d.dtype == torch.uint8
+        got.append(ctx.sequence_run_device(d.data_ptr(), d.shape[0], w, h, w, K02))
+        torch.cuda.synchronize()
+    ctx.close()
+    got = np.concatenate(got)
+    assert _records_equal(got, ref)

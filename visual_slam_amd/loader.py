@@ -1,0 +1,121 @@
+"""Image loader feeding the batched entry points.
+
+The reference decodes every frame with `cv2.imread(path, cv2.IMREAD_GRAYSCALE)` inside
+`get_matches` (/root/reference/libs/vo_utils.py:94-95), twice per frame, on the thread that
+also runs the whole pipeline; the path list comes from `load_image_paths` (:65-71).  At the
+GPU path's rate the PNG inflate (about 280 KB per KITTI frame) is the bottleneck, so decoding
+is taken off the critical path:
+
+  * a pool of decoder threads (Pillow's decoders release the GIL) fills chunks of frames,
+  * each chunk lands in a page-locked (pinned) staging buffer of a small ring,
+  * and is copied to the GPU on a side stream, so the copy of chunk k+1 and the decode of
+    chunk k+2 overlap `vo_sequence_run_device` / `vo_pairs_run_device` on chunk k.
+
+Decoded pixels are exactly Pillow's 8-bit gray ("L") conversion = cv2's IMREAD_GRAYSCALE for
+8-bit gray PNGs; colour inputs go through Pillow's ITU-R 601 luma, which can
+differ from cv2's fixed-point BGR2GRAY by one grey level -- KITTI odometry frames are gray.
+"""
+import os
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+
+
+def load_image_paths(filepath):
+    """libs/vo_utils.py:65-71: sorted .png / .jpg files of a directory."""
+    return [os.path.join(filepath, f) for f in sorted(os.listdir(filepath)) if f.endswith('.png') or f.endswith('.jpg')]
+
+
+def decode_gray(path):
+    """cv2.imread(path, cv2.IMREAD_GRAYSCALE) -> uint8 (h, w)."""
+    from PIL import Image
+
+    with Image.open(path) as im:
+        if im.mode != "L":
+            im = im.convert("L")
+        return np.asarray(im)
+
+
+class FrameLoader:
+    """Iterate over a list of image files in chunks of `chunk` frames, `overlap` frames shared
+    between consecutive chunks (1 for sequences: pair i needs frames i and i+1).
+
+    device=None yields numpy arrays [n,h,w]; device="cuda:0" (or an int) yields torch uint8
+    tensors on that GPU, uploaded from pinned memory on a side stream `depth` chunks ahead."""
+
+    def __init__(self, paths, chunk=64, overlap=0, workers=None, depth=2, device=None):
+        if chunk <= overlap:
+            raise ValueError("chunk must exceed overlap")
+        self.paths = list(paths)
+        self.chunk, self.overlap, self.depth = int(chunk), int(overlap), max(1, int(depth))
+        self.workers = workers or max(1, min(16, (os.cpu_count() or 2) - 1))
+        self.device = device
+        starts, s, n = [], 0, len(self.paths)
+        while s < n and (not starts or s + self.overlap < n):
+            starts.append(s)
+            s += self.chunk - self.overlap
+        self.chunks = [(a, min(a + self.chunk, n)) for a in starts]
+
+    def __len__(self):
+        return len(self.chunks)
+
+    def __iter__(self):
+        if not self.paths:
+            return
+        pool = ThreadPoolExecutor(self.workers)
+        try:
+            h, w = decode_gray(self.paths[0]).shape
+            torch = stream = None
+            ring = []
+            if self.device is not None:
+                import torch
+                dev = torch.device("cuda", self.device) if isinstance(self.device, int) else torch.device(self.device)
+                stream = torch.cuda.Stream(device=dev)
+                ring = [torch.empty((self.chunk, h, w), dtype=torch.uint8).pin_memory() for _ in range(self.depth + 1)]
+                ring_ev = [None] * len(ring)
+
+            def submit(ci):
+                a, b = self.chunks[ci]
+                return [pool.submit(decode_gray, p) for p in self.paths[a:b]]
+
+            def finish(ci, futs):
+                imgs = [f.result() for f in futs]
+                for k, im in enumerate(imgs):
+                    if im.shape != (h, w):
+                        raise ValueError("%s: frame size %s differs from %s" % (self.paths[self.chunks[ci][0] + k], im.shape, (h, w)))
+                if torch is None:
+                    return np.stack(imgs)
+                slot = ci % len(ring)
+                if ring_ev[slot] is not None:
+                    ring_ev[slot].synchronize()      # the upload that last used this staging buffer has finished
+                host = ring[slot][: len(imgs)]
+                for k, im in enumerate(imgs):
+                    host[k].numpy()[...] = im
+                with torch.cuda.stream(stream):
+                    d = host.to(dev, non_blocking=True)
+                    ev = torch.cuda.Event()
+                    ev.record(stream)
+                ring_ev[slot] = ev
+                return d, ev
+
+            pending = {}
+            uploaded = {}
+            nxt = 0
+            for ci in range(len(self.chunks)):
+                while nxt < len(self.chunks) and nxt <= ci + self.depth:
+                    pending[nxt] = submit(nxt)
+                    nxt += 1
+                # decode-complete + upload issue runs one chunk ahead, so the copy of chunk ci+1 overlaps the
+                # consumer's work on chunk ci
+                for cj in (ci, ci + 1):
+                    if cj < len(self.chunks) and cj not in uploaded:
+                        uploaded[cj] = finish(cj, pending.pop(cj))
+                out = uploaded.pop(ci)
+                if torch is None:
+                    yield out
+                else:
+                    d, ev = out
+                    ev.synchronize()      # the library launches on its own stream: hand over completed uploads only
+                    yield d
+        finally:
+            pool.shutdown(wait=True, cancel_futures=True)
