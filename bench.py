@@ -76,9 +76,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--pairs", type=int, default=2048, help="frame pairs per GPU per step")
     ap.add_argument("--distinct", type=int, default=256, help="distinct seeded pairs generated per GPU (tiled up to --pairs)")
-    ap.add_argument("--chunk", type=int, default=64, help="pairs per detect/match launch wave")
+    ap.add_argument("--chunk", type=int, default=32, help="pairs per detect/match launch wave")
     ap.add_argument("--workers", type=int, default=0, help="host processes for input generation (0 = auto; use 1 under rocprofv3)")
-    ap.add_argument("--streams", type=int, default=1,
+    ap.add_argument("--streams", type=int, default=2,
                     help="contexts (one HIP stream and workspace each) driven by one host thread each; the batch is split between them")
     ap.add_argument("--ba", action="store_true",
                     help="extra diagnostic: time the BA residual/Jacobian pass of configs[4] (1000 poses x 200k points x 5 obs, points "
