@@ -662,24 +662,16 @@ __device__ int sel_partition(float* key, uint32_t* pay, uint32_t* lpos, uint32_t
 }
 
 // KeyPointsFilter::retainBest(list, mult*quota) for every (frame, level) list of the chunk.
+// The replay is a chain of ~log2(n) partitions, each a handful of dependent passes over the list, so
+// it is bound by memory latency: lists of up to CAP candidates are therefore copied to LDS, permuted
+// there (same code through generic pointers) and only the kept prefix is written back; longer lists
+// run in place in global memory.  Measured: the second retainBest (lists <= 2*quota, CAP 2048 = 32 KB, five
+// workgroups per CU) drops from 0.056 to 0.042 ms; for the first one (up to ~6000 FAST candidates per
+// level) the 64-128 KB of LDS cut residency to one or two workgroups per CU and the launch got SLOWER
+// (0.12 -> 0.17-0.19 ms), so it stays in global memory (CAP 64).
 template <int NT>
-__global__ __launch_bounds__(NT) void k_select(const Geom* __restrict__ g, float* key, uint32_t* pay, uint32_t* lpos, uint32_t* rpos,
-                                               const int* __restrict__ cnt_in, int* __restrict__ cnt_out, int mult) {
-    __shared__ int s_wl[NT / 64], s_wr[NT / 64], s_K;
-    const int l = blockIdx.x, f = blockIdx.y, tid = threadIdx.x;
-    const LevelGeom& L = g->lv[l];
-    const long base = (long)f * g->cand_frame + L.cand_ofs;
-    key += base; pay += base; lpos += base; rpos += base;
-    const int n = cnt_in[f * VO_MAX_LEVELS + l];
-    const int np = mult * L.quota;
-    if (!(n > np)) {
-        if (tid == 0) cnt_out[f * VO_MAX_LEVELS + l] = n;
-        return;
-    }
-    if (np == 0) {
-        if (tid == 0) cnt_out[f * VO_MAX_LEVELS + l] = 0;
-        return;
-    }
+__device__ int retain_best(float* key, uint32_t* pay, uint32_t* lpos, uint32_t* rpos, int n, int np, int* s_wl, int* s_wr, int* s_K) {
+    const int tid = threadIdx.x;
     int first = 0, last = n;
     const int nth = np - 1;
     int depth = 2 * (31 - __clz(n));
@@ -695,15 +687,47 @@ __global__ __launch_bounds__(NT) void k_select(const Geom* __restrict__ g, float
         if (tid == 0) sel_median_to_first(key, pay, first, first + 1, first + (last - first) / 2, last - 1);
         __syncthreads();
         const float p = key[first];
-        const int cut = sel_partition<NT, 0>(key, pay, lpos, rpos, first + 1, last, p, s_wl, s_wr, &s_K);
+        const int cut = sel_partition<NT, 0>(key, pay, lpos, rpos, first + 1, last, p, s_wl, s_wr, s_K);
         if (cut <= nth) first = cut;
         else last = cut;
     }
     if (!heap_done && tid == 0) sel_insertion_sort(key, pay, first, last);
     __syncthreads();
     const float amb = key[np - 1];
-    const int totT = sel_partition<NT, 1>(key, pay, lpos, rpos, np, n, amb, s_wl, s_wr, &s_K);
-    if (tid == 0) cnt_out[f * VO_MAX_LEVELS + l] = np + totT;
+    const int totT = sel_partition<NT, 1>(key, pay, lpos, rpos, np, n, amb, s_wl, s_wr, s_K);
+    return np + totT;
+}
+
+template <int NT, int CAP>
+__global__ __launch_bounds__(NT) void k_select(const Geom* __restrict__ g, float* key, uint32_t* pay, uint32_t* lpos, uint32_t* rpos,
+                                               const int* __restrict__ cnt_in, int* __restrict__ cnt_out, int mult) {
+    __shared__ int s_wl[NT / 64], s_wr[NT / 64], s_K;
+    __shared__ float l_key[CAP];
+    __shared__ uint32_t l_pay[CAP], l_lpos[CAP], l_rpos[CAP];
+    const int l = blockIdx.x, f = blockIdx.y, tid = threadIdx.x;
+    const LevelGeom& L = g->lv[l];
+    const long base = (long)f * g->cand_frame + L.cand_ofs;
+    key += base; pay += base; lpos += base; rpos += base;
+    const int n = cnt_in[f * VO_MAX_LEVELS + l];
+    const int np = mult * L.quota;
+    if (!(n > np)) {
+        if (tid == 0) cnt_out[f * VO_MAX_LEVELS + l] = n;
+        return;
+    }
+    if (np == 0) {
+        if (tid == 0) cnt_out[f * VO_MAX_LEVELS + l] = 0;
+        return;
+    }
+    int kept;
+    if (n <= CAP) {
+        for (int i = tid; i < n; i += NT) { l_key[i] = key[i]; l_pay[i] = pay[i]; }
+        __syncthreads();
+        kept = retain_best<NT>(l_key, l_pay, l_lpos, l_rpos, n, np, s_wl, s_wr, &s_K);
+        for (int i = tid; i < kept; i += NT) { key[i] = l_key[i]; pay[i] = l_pay[i]; }
+    } else {
+        kept = retain_best<NT>(key, pay, lpos, rpos, n, np, s_wl, s_wr, &s_K);
+    }
+    if (tid == 0) cnt_out[f * VO_MAX_LEVELS + l] = kept;
 }
 
 // ------------------------------------------------------------------ Harris (HarrisResponses, blockSize 7)
@@ -1148,10 +1172,10 @@ int vo_launch_detect(vo_ctx* c, const FrameSrc& src, int F, hipStream_t st) {
                            (const uint32_t*)c->d_seg_ofs.p, key, payload, F));
     }
     if (c->debug_stop == 1) { HIP_TRY(c, hipGetLastError()); return VO_OK; }
-    KT(c, st, VO_K_SELECT1, hipLaunchKernelGGL(k_select<512>, dim3(g.nlevels, F), dim3(512), 0, st, dg, key, payload, (uint32_t*)c->d_lpos.p, (uint32_t*)c->d_rpos.p, cnt_fast, cnt_sel1, 2));
+    KT(c, st, VO_K_SELECT1, hipLaunchKernelGGL((k_select<256, 64>), dim3(g.nlevels, F), dim3(256), 0, st, dg, key, payload, (uint32_t*)c->d_lpos.p, (uint32_t*)c->d_rpos.p, cnt_fast, cnt_sel1, 2));
     KT(c, st, VO_K_HARRIS, hipLaunchKernelGGL(k_harris, dim3(pad8(HARRIS_BX * g.nlevels * F)), dim3(256), 0, st, dg, src, pyr, cnt_sel1, key, payload, F));
     if (c->debug_stop == 2) { HIP_TRY(c, hipGetLastError()); return VO_OK; }
-    KT(c, st, VO_K_SELECT2, hipLaunchKernelGGL(k_select<512>, dim3(g.nlevels, F), dim3(512), 0, st, dg, key, payload, (uint32_t*)c->d_lpos.p, (uint32_t*)c->d_rpos.p, cnt_sel1, cnt_sel2, 1));
+    KT(c, st, VO_K_SELECT2, hipLaunchKernelGGL((k_select<256, 2048>), dim3(g.nlevels, F), dim3(256), 0, st, dg, key, payload, (uint32_t*)c->d_lpos.p, (uint32_t*)c->d_rpos.p, cnt_sel1, cnt_sel2, 1));
     KT(c, st, VO_K_ORIENT, hipLaunchKernelGGL(k_orient, dim3(pad8(ORIENT_BX * g.nlevels * F)), dim3(256), 0, st, dg, src, pyr, cnt_sel2, key, payload, (vo_keypoint*)c->d_kp.p,
                        (uint32_t*)c->d_kplvl.p, (int*)c->d_nkp.p, (int*)c->d_frame_status.p, F));
     BlurK bk;
