@@ -31,6 +31,41 @@ def test_match_knn2_bit_exact(ctx, oracle):
             assert np.array_equal(a, b), (nq, nt)
 
 
+def test_match_extremes_and_collisions():
+    """Matrix-core matcher corner cases vs a numpy brute force: distances 0 and 256 (all-zero / all-one
+    descriptors), every train identical (ties broken by lowest trainIdx), train counts around the 32-row
+    block and the 2016-train segment limits, query counts around the 384-query workgroup."""
+    from visual_slam_amd import _lib
+    rng = np.random.default_rng(7)
+    LUT = np.array([bin(i).count("1") for i in range(256)], np.int32)
+
+    def brute(q, t):
+        d = LUT[q[:, None, :] ^ t[None, :, :]].sum(2)
+        key = d.astype(np.int64) * 65536 + np.arange(t.shape[0])[None, :]
+        o = np.argsort(key, axis=1, kind="stable")[:, :2]
+        return o[:, 0], np.take_along_axis(d, o[:, :1], 1)[:, 0], o[:, 1], np.take_along_axis(d, o[:, 1:2], 1)[:, 0]
+
+    c = _lib.Context(max_w=640, max_h=480, chunk_pairs=1, max_pairs=1, nfeatures=8000)   # kp_cap 9024 -> 5 train segments
+    try:
+        cases = []
+        q = rng.integers(0, 256, (383, 32), dtype=np.uint8); t = np.zeros((33, 32), np.uint8); t[:] = 0xFF; q[0] = 0; q[1] = 0xFF
+        cases.append((q, t))                                             # identical trains, d = 256 and d = 0
+        q = rng.integers(0, 256, (385, 32), dtype=np.uint8); t = rng.integers(0, 256, (2, 32), dtype=np.uint8)
+        cases.append((q, t))                                             # the minimum train set
+        for nt in (31, 32, 63, 64, 65, 2016 * 2 + 1, 8063):
+            q = rng.integers(0, 256, (97, 32), dtype=np.uint8)
+            t = rng.integers(0, 4, (nt, 32), dtype=np.uint8)              # few distinct bits -> many distance ties
+            t[nt - 1] = q[3]                                              # an exact match in the ragged last block
+            cases.append((q, t))
+        for q, t in cases:
+            got = c.match_knn2(q, t)
+            ref = brute(q, t)
+            for a, b in zip(got, ref):
+                assert np.array_equal(np.asarray(a, np.int64), np.asarray(b, np.int64)), (q.shape, t.shape)
+    finally:
+        c.close()
+
+
 def test_match_on_real_descriptors_and_ratio(ctx, oracle, kitti02):
     k1, f1 = oracle.orb_detect_compute(kitti02[0])
     k2, f2 = oracle.orb_detect_compute(kitti02[1])
