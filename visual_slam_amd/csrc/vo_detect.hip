@@ -277,9 +277,10 @@ __global__ __launch_bounds__(256) void k_fast_tiles(const Geom* __restrict__ g, 
                                                     uint8_t* __restrict__ seg_cnt, int nframes) {
     __shared__ __attribute__((aligned(16))) uint8_t px[PXR * PXP];
     __shared__ __attribute__((aligned(16))) uint8_t sc[32 * SCP + 8];      // scores of the 64 x 32 positions
-    __shared__ __attribute__((aligned(16))) uint8_t km[32 * 64];           // kept (NMS + border) scores of the 60 x 30 outputs
+    __shared__ uint32_t bm[64];          // survivors (NMS + border) of the 60 x 30 outputs, one bit each: row r = dwords 2r, 2r+1
+    __shared__ int bmpre[64];            // exclusive prefix of the popcounts of bm
     __shared__ uint16_t queue[FQ_CAP];   // brighter-arc candidates from the front, darker-arc candidates from the back
-    __shared__ int wtot[4], qcnt;        // qcnt: brighter count | darker count << 16
+    __shared__ int qcnt;                 // brighter count | darker count << 16
     const VBlock vb = xcd_block(g->ntiles, 1, nframes);
     if (!vb.valid) return;
     const int t = vb.x, f = vb.f, tid = threadIdx.x;
@@ -294,6 +295,7 @@ __global__ __launch_bounds__(256) void k_fast_tiles(const Geom* __restrict__ g, 
     // 252 lanes cover 14 rows per pass
     const int xa = x0 - 4 - PXO;
     if (tid == 0) qcnt = 0;
+    if (tid >= 192) bm[tid - 192] = 0;
     if (tid < 252) {
         const int r0 = tid / 18, k = tid - r0 * 18;
         const int x = xa + 4 * k;
@@ -340,7 +342,6 @@ __global__ __launch_bounds__(256) void k_fast_tiles(const Geom* __restrict__ g, 
         const uint32_t P21 = rowP2[1], P22 = rowP2[2], M21 = rowM2[1], M22 = rowM2[2];
         const uint32_t P31 = rowP3[1], P32 = rowP3[2], M31 = rowM3[1], M32 = rowM3[2];
         *reinterpret_cast<uint32_t*>(&sc[r * SCP + k4]) = 0;
-        *reinterpret_cast<uint32_t*>(&km[r * 64 + k4]) = 0;
         // position i: centre = LDS col k4+6+i;  mm = min over pairs of max, xm = max over pairs of min
 #define PRETEST(i, v, a0, a8, a2, a10, a4, a12, a6, a14)                                                             \
         const int mm##i = (int)min(min(max(a0, a8), max(a2, a10)), min(max(a4, a12), max(a6, a14)));                  \
@@ -390,7 +391,8 @@ __global__ __launch_bounds__(256) void k_fast_tiles(const Geom* __restrict__ g, 
         sc[i] = (uint8_t)max((int)sc[i], best > thr ? best - 1 : 0);
     }
     __syncthreads();
-    // Stage 3: strict 3x3 non-max suppression + border filter, only at the queued positions
+    // Stage 3: strict 3x3 non-max suppression + border filter, only at the queued positions; a survivor sets
+    // its bit in a 60 x 30 bitmap (row r = dwords 2r, 2r+1), whose bit order is raster order
     for (int q = tid; q < nb + nd; q += 256) {
         const int i = q < nb ? queue[q] : queue[FQ_CAP - 1 - (q - nb)];
         const int r = i >> 6, c = i & 63;                      // score position; output (r-1, c-1)
@@ -399,48 +401,29 @@ __global__ __launch_bounds__(256) void k_fast_tiles(const Geom* __restrict__ g, 
         const int xi = x0 - 1 + c, yi = y0 - 1 + r;
         if (s != 0 && r >= 1 && r <= VO_TILE_H && c >= 1 && c <= VO_TILE_W && xi < Lw - VO_EDGE && yi < Lh - VO_EDGE &&
             s > s0[-1] && s > s0[1] && s > s0[-SCP - 1] && s > s0[-SCP] && s > s0[-SCP + 1] && s > s0[SCP - 1] && s > s0[SCP] && s > s0[SCP + 1])
-            km[(r - 1) * 64 + (c - 1)] = (uint8_t)s;
+            atomicOr(&bm[(r - 1) * 2 + ((c - 1) >> 5)], 1u << ((c - 1) & 31));
     }
     __syncthreads();
-    // Stage 4: ordered compaction.  A lane takes 4 adjacent pixels of output rows tid/16 and 16 + tid/16
-    // (16 groups per row), so (row block, tid) order is raster order; both blocks share one packed scan.
-    uint32_t ent[2][2];
-    int cnt[2];
-#pragma unroll
-    for (int it = 0; it < 2; it++) {
-        const int r = it * 16 + (tid >> 4), c4 = (tid & 15) * 4;
-        const uint32_t kd = *reinterpret_cast<const uint32_t*>(&km[r * 64 + c4]);
-        cnt[it] = 0;
-        ent[it][0] = ent[it][1] = 0;
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const uint32_t sv = BYTE(kd, j);
-            if (sv != 0 && cnt[it] < 2) ent[it][cnt[it]++] = PACK_XYS(x0 + c4 + j, y0 + r, sv);
-        }
+    // Stage 4: ranks from the bitmap.  The first wavefront scans the 60 dword popcounts (exclusive prefix per
+    // dword, count per row); then every survivor's rank = prefix of its dword + set bits below it.
+    if (wave == 0) {
+        const int v = lane < 2 * VO_TILE_H ? (int)__popc(bm[lane]) : 0;
+        const int incl = wave_incl_scan(v);
+        bmpre[lane] = incl - v;
+        const int nxt = __shfl_down(v, 1);
+        const int r = lane >> 1;
+        if ((lane & 1) == 0 && r < VO_TILE_H && td.ty * VO_TILE_H + r < L.ih)
+            seg_cnt[(long)f * g->nsegs + L.seg_base + (long)(td.ty * VO_TILE_H + r) * L.ntx + td.tx] = (uint8_t)(v + nxt);
     }
-    const int incl = wave_incl_scan(cnt[0] | (cnt[1] << 16));
-    if (lane == 63) wtot[wave] = incl;
     __syncthreads();
     uint32_t* tl = tile_list + ((long)f * g->ntiles + t) * VO_TILE_CAP;
-    int below = 0, all = 0;
-#pragma unroll
-    for (int w2 = 0; w2 < 4; w2++) {
-        const int wt = wtot[w2];
-        all += wt;
-        if (w2 < wave) below += wt;
-    }
-    const int row_end = __shfl_down(incl, 15);
-#pragma unroll
-    for (int it = 0; it < 2; it++) {
-        const int inc = (it ? incl >> 16 : incl & 0xFFFF);
-        const int excl = (it ? (all & 0xFFFF) + (below >> 16) : (below & 0xFFFF)) + inc - cnt[it];
-        if (cnt[it] > 0) tl[excl] = ent[it][0];
-        if (cnt[it] > 1) tl[excl + 1] = ent[it][1];
-        const int r = it * 16 + (tid >> 4);
-        if ((tid & 15) == 0 && r < VO_TILE_H && td.ty * VO_TILE_H + r < L.ih) {
-            const int rc = (it ? row_end >> 16 : row_end & 0xFFFF) - (inc - cnt[it]);
-            seg_cnt[(long)f * g->nsegs + L.seg_base + (long)(td.ty * VO_TILE_H + r) * L.ntx + td.tx] = (uint8_t)rc;
-        }
+    for (int q = tid; q < nb + nd; q += 256) {
+        const int i = q < nb ? queue[q] : queue[FQ_CAP - 1 - (q - nb)];
+        const int r = (i >> 6) - 1, c = (i & 63) - 1;          // output position
+        if (r < 0 || r >= VO_TILE_H || c < 0 || c >= VO_TILE_W) continue;
+        const int d = r * 2 + (c >> 5), bit = c & 31;
+        const uint32_t w = bm[d];
+        if ((w >> bit) & 1u) tl[bmpre[d] + (int)__popc(w & ((1u << bit) - 1u))] = PACK_XYS(x0 + c, y0 + r, sc[i]);
     }
 }
 
