@@ -88,7 +88,12 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--sequence", action="store_true",
                     help="extra diagnostic: also time vo_sequence_run_device on the A frames taken as one sequence (each frame extracted once)")
+    ap.add_argument("--config4", action="store_true",
+                    help="diagnostic: run configs[3] instead (3840x2160 frames, 20000 ORB features; use e.g. --pairs 16 --distinct 4 --chunk 4)")
     args = ap.parse_args()
+    global W_IMG, H_IMG, NFEAT
+    if args.config4:
+        W_IMG, H_IMG, NFEAT = 3840, 2160, 20000
 
     import torch
     import torch.distributed as dist
@@ -113,12 +118,12 @@ def main():
         reps = (B + nd - 1) // nd
         imgsA = np.concatenate([imgsA] * reps)[:B]
         imgsB = np.concatenate([imgsB] * reps)[:B]
-    K = synth.K_KITTI02
+    K = synth.config_K(W_IMG, H_IMG)
     dA = torch.from_numpy(imgsA).cuda()
     dB = torch.from_numpy(imgsB).cuda()
     S = max(1, min(args.streams, B))
     bounds = [parallel.shard_range(B, i, S) for i in range(S)]
-    ctxs = [_lib.Context(max_w=W_IMG, max_h=H_IMG, chunk_pairs=min(args.chunk, hi - lo), max_pairs=hi - lo, device=local_rank) for lo, hi in bounds]
+    ctxs = [_lib.Context(max_w=W_IMG, max_h=H_IMG, chunk_pairs=min(args.chunk, hi - lo), max_pairs=hi - lo, device=local_rank, nfeatures=NFEAT) for lo, hi in bounds]
     ctx = ctxs[0]
     fsz = W_IMG * H_IMG
     pool = None
@@ -248,7 +253,8 @@ def main():
             "value": round(value, 2), "unit": "frame-pairs/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8/int32 detect+match, f64 pose", "data": "synthetic",
-            "config": {"workload": "configs[2]: batch of synthetic 1241x376 pairs (configs[1] generator, seeds 0..), 3000 ORB features, 8 levels",
+            "config": {"workload": ("configs[2]: batch of synthetic 1241x376 pairs (configs[1] generator, seeds 0..), 3000 ORB features, 8 levels" if not args.config4 else
+                                    "configs[3] (diagnostic): synthetic 3840x2160 pairs, 20000 ORB features, 8 levels"),
                        "pairs_per_gpu": B, "distinct_pairs_per_gpu": nd, "global_pairs": world * B, "chunk_pairs": min(args.chunk, B), "streams_per_gpu": S, "parallelism": "pairs sharded over ranks, no collective",
                        "pairs_ok": ok, "pairs_total": int(len(res))},
             "roofline": roofline, "cpu_baseline": cpu, "sequence_mode": seq, "ba_pass": ba_out, "kernels": kernels,

@@ -80,12 +80,19 @@ def warp_b(img_a, K):
     return np.clip(np.rint(top * (1 - fy) + bot * fy), 0, 255).astype(np.uint8).reshape(h, w)
 
 
+def config_K(w, h):
+    """Intrinsics of the generator at frame size w x h: KITTI 02 scaled by w / 1241."""
+    if w == 1241:
+        return K_KITTI02
+    K = K_KITTI02 * np.array([[w / 1241.0], [w / 1241.0], [1.0]])
+    K[1, 2] = h / 2.0
+    return K
+
+
 def make_pair(seed, w=1241, h=376, K=None):
     """Returns (frame A, frame B, K, R, t) for one seed."""
     if K is None:
-        K = K_KITTI02 * np.array([[w / 1241.0], [w / 1241.0], [1.0]]) if w != 1241 else K_KITTI02
-        if w != 1241:
-            K = K.copy(); K[1, 2] = h / 2.0
+        K = config_K(w, h)
     rng = np.random.default_rng(seed)
     a = frame_a(rng, w, h)
     b = warp_b(a, K)
