@@ -788,6 +788,7 @@ __constant__ int c_umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9
 // One wavefront per keypoint: lane = (row group, 4-byte column group); the 31 x 32-byte window
 // of the disc is read as 4 unaligned dwords per lane, integer moments reduced across the wave.
 #define ORIENT_BX 16   // workgroups per (level, frame)
+#define ORIENT_KPB 64  // keypoints per workgroup batch
 __global__ __launch_bounds__(256) void k_orient(const Geom* __restrict__ g, FrameSrc src, const uint8_t* __restrict__ pyr,
                                                 const int* __restrict__ cnt_sel2, const float* __restrict__ key,
                                                 const uint32_t* __restrict__ payload, vo_keypoint* __restrict__ kps,
@@ -812,52 +813,66 @@ __global__ __launch_bounds__(256) void k_orient(const Geom* __restrict__ g, Fram
     const long cb = (long)f * g->cand_frame + L.cand_ofs;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int rg = lane >> 3, u0 = -16 + 4 * (lane & 7);
-    // per-lane row offsets and disc limits of its (up to) 4 rows
-    int vrow[4], um[4];
+    // A lane owns 4 adjacent columns u0..u0+3 of (up to) 4 rows v = -15 + rg + 8*it of the 31 x 31 window.
+    // Per row: the disc limit |u| <= umax[|v|] becomes a byte mask, so the row's contribution is
+    //   rs = b0+b1+b2+b3 (v_sad_u8),  sum u*b = u0*rs + (0*b0+1*b1+2*b2+3*b3) (v_dot4_u32_u8).
+    int vrow[4];
+    uint32_t bmask[4];
 #pragma unroll
     for (int it = 0; it < 4; it++) {
         const int v = -15 + rg + 8 * it;
-        vrow[it] = v;
-        um[it] = v <= 15 ? c_umax[v < 0 ? -v : v] : -1;
-    }
-    for (int i = vb.x * 4 + wave; i < n; i += ORIENT_BX * 4) {
-        const uint32_t p = payload[cb + i];
-        const int x0 = UNPACK_X(p), y0 = UNPACK_Y(p);
-        const uint8_t* center = img + (long)y0 * pitch + x0;
-        int m10 = 0, m01 = 0;
+        const int um = v <= 15 ? c_umax[v < 0 ? -v : v] : -1;
+        vrow[it] = min(v, 15);     // row 16 does not exist: its mask is empty, the load stays inside the window
+        uint32_t m = 0;
 #pragma unroll
-        for (int it = 0; it < 4; it++) {
-            if (um[it] >= 0) {
+        for (int j = 0; j < 4; j++) {
+            const int u = u0 + j;
+            if ((u < 0 ? -u : u) <= um) m |= 0xFFu << (8 * j);
+        }
+        bmask[it] = m;
+    }
+    __shared__ int s_m10[ORIENT_KPB], s_m01[ORIENT_KPB];
+    // batches of 64 keypoints: each wavefront reduces the moments of 16 of them, then one lane per keypoint
+    // does the arctangent and writes the KeyPoint record
+    for (int i0 = vb.x * ORIENT_KPB; i0 < n; i0 += ORIENT_BX * ORIENT_KPB) {
+        uint32_t my_p = 0;
+        if (lane < ORIENT_KPB / 4 && i0 + wave + 4 * lane < n) my_p = payload[cb + i0 + wave + 4 * lane];
+        for (int j = 0; j < ORIENT_KPB / 4; j++) {
+            const int kk = wave + 4 * j;
+            if (i0 + kk >= n) break;
+            const uint32_t p = __shfl(my_p, j);
+            const uint8_t* center = img + (long)UNPACK_Y(p) * pitch + UNPACK_X(p);
+            int m10 = 0, m01 = 0;
+#pragma unroll
+            for (int it = 0; it < 4; it++) {
                 uint32_t d;
                 __builtin_memcpy(&d, center + (long)vrow[it] * pitch + u0, 4);
-                int rs = 0;
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const int u = u0 + j;
-                    const int val = ((u < 0 ? -u : u) <= um[it]) ? (int)((d >> (8 * j)) & 0xFF) : 0;
-                    m10 += u * val;
-                    rs += val;
-                }
+                d &= bmask[it];
+                const int rs = (int)__builtin_amdgcn_sad_u8(d, 0u, 0u);
+                m10 += u0 * rs + (int)__builtin_amdgcn_udot4(d, 0x03020100u, 0u, false);
                 m01 += vrow[it] * rs;
             }
+            m10 = wave_incl_scan(m10);
+            m01 = wave_incl_scan(m01);
+            if (lane == 63) { s_m10[kk] = m10; s_m01[kk] = m01; }
         }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            m10 += __shfl_xor(m10, o);
-            m01 += __shfl_xor(m01, o);
-        }
-        if (lane == 0 && off + i < g->kp_cap) {
+        __syncthreads();
+        const int i = i0 + threadIdx.x;
+        if (threadIdx.x < ORIENT_KPB && i < n && off + i < g->kp_cap) {
+            const uint32_t p = payload[cb + i];
+            const int x0 = UNPACK_X(p), y0 = UNPACK_Y(p);
             vo_keypoint k;
             k.x = (float)x0 * L.scale;
             k.y = (float)y0 * L.scale;
             k.size = 31 * L.scale;
-            k.angle = fast_atan2_deg((float)m01, (float)m10, g->fma != 0);
+            k.angle = fast_atan2_deg((float)s_m01[threadIdx.x], (float)s_m10[threadIdx.x], g->fma != 0);
             k.response = key[cb + i];
             k.octave = l;
             const long o = (long)f * g->kp_cap + off + i;
             kps[o] = k;
             kplvl[o] = PACK_XYS(x0, y0, l);
         }
+        __syncthreads();
     }
 }
 
