@@ -166,55 +166,72 @@ int vo_build_geometry(vo_ctx* c, int w, int h) {
 // One lane makes 4 adjacent pixels: one 16-byte coefficient load, one 8-byte load from each of
 // the two source rows (the 4 outputs read at most 7 consecutive source bytes for scale <= 2),
 // one dword store.
+#define PYR_ROWS 4   // output rows per lane: their source loads are issued together (the kernel is latency bound)
 __global__ __launch_bounds__(256) void k_pyramid(const Geom* __restrict__ g, FrameSrc src, uint8_t* __restrict__ pyr,
                                                  const ResizeCoef* __restrict__ rt, int l) {
     const LevelGeom& L = g->lv[l];
     const int f = blockIdx.z;
     const int x4 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
-    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (y >= L.h || x4 >= L.w) return;
+    const int y0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * PYR_ROWS;
+    if (y0 >= L.h || x4 >= L.w) return;
     int spitch;
     const uint8_t* sp = level_ptr(g, src, pyr, f, l - 1, spitch);
     const int sw = g->lv[l - 1].w, sh = g->lv[l - 1].h;
-    const uint32_t cy = rt[L.ytab + y];
-    const int oy = (int)(cy & 0xFFFF);
-    const uint8_t* r0 = sp + (long)oy * spitch;
-    const uint8_t* r1 = sp + (long)min(oy + 1, sh - 1) * spitch;
-    const uint32_t c1y = cy >> 16, c0y = 256 - c1y;
     const uint4 cx4 = *reinterpret_cast<const uint4*>(rt + L.xtab + x4);
     const uint32_t cx[4] = {cx4.x, cx4.y, cx4.z, cx4.w};
     const int nvalid = min(4, L.w - x4);
     const int o0 = (int)(cx[0] & 0xFFFF);
     const int olast = (int)(cx[nvalid - 1] & 0xFFFF);
-    uint32_t packed = 0;
-    if (olast + 1 - o0 < 8 && o0 + 8 <= sw) {
-        unsigned long long a, b;
-        __builtin_memcpy(&a, r0 + o0, 8);
-        __builtin_memcpy(&b, r1 + o0, 8);
+    uint8_t* dp = pyr + (long)f * g->pyr_frame + L.pyr_ofs + (long)y0 * L.pitch + x4;
+    uint32_t cyv[PYR_ROWS];
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            if (i < nvalid) {
-                const int rel = (int)(cx[i] & 0xFFFF) - o0;
-                const uint32_t c1 = cx[i] >> 16, c0 = 256 - c1;
-                const uint32_t p00 = (uint32_t)(a >> (8 * rel)) & 0xFF, p01 = (uint32_t)(a >> (8 * rel + 8)) & 0xFF;
-                const uint32_t p10 = (uint32_t)(b >> (8 * rel)) & 0xFF, p11 = (uint32_t)(b >> (8 * rel + 8)) & 0xFF;
-                const uint32_t h0 = c0 * p00 + c1 * p01, h1 = c0 * p10 + c1 * p11;
-                packed |= ((c0y * h0 + c1y * h1 + 32768u) >> 16) << (8 * i);
+    for (int r = 0; r < PYR_ROWS; r++) cyv[r] = rt[L.ytab + min(y0 + r, L.h - 1)];
+    if (olast + 1 - o0 < 8 && o0 + 8 <= sw) {
+        unsigned long long a[PYR_ROWS], b[PYR_ROWS];
+#pragma unroll
+        for (int r = 0; r < PYR_ROWS; r++) {
+            const int oy = (int)(cyv[r] & 0xFFFF);
+            __builtin_memcpy(&a[r], sp + (long)oy * spitch + o0, 8);
+            __builtin_memcpy(&b[r], sp + (long)min(oy + 1, sh - 1) * spitch + o0, 8);
+        }
+#pragma unroll
+        for (int r = 0; r < PYR_ROWS; r++) {
+            const uint32_t c1y = cyv[r] >> 16, c0y = 256 - c1y;
+            uint32_t packed = 0;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                if (i < nvalid) {
+                    const int rel = (int)(cx[i] & 0xFFFF) - o0;
+                    const uint32_t c1 = cx[i] >> 16, c0 = 256 - c1;
+                    const uint32_t p00 = (uint32_t)(a[r] >> (8 * rel)) & 0xFF, p01 = (uint32_t)(a[r] >> (8 * rel + 8)) & 0xFF;
+                    const uint32_t p10 = (uint32_t)(b[r] >> (8 * rel)) & 0xFF, p11 = (uint32_t)(b[r] >> (8 * rel + 8)) & 0xFF;
+                    const uint32_t h0 = c0 * p00 + c1 * p01, h1 = c0 * p10 + c1 * p11;
+                    packed |= ((c0y * h0 + c1y * h1 + 32768u) >> 16) << (8 * i);
+                }
             }
+            if (y0 + r < L.h) *reinterpret_cast<uint32_t*>(dp + (long)r * L.pitch) = packed;
         }
     } else {
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            if (i < nvalid) {
-                const int ox = (int)(cx[i] & 0xFFFF), ox1 = min(ox + 1, sw - 1);
-                const uint32_t c1 = cx[i] >> 16, c0 = 256 - c1;
-                const uint32_t h0 = c0 * r0[ox] + c1 * r0[ox1], h1 = c0 * r1[ox] + c1 * r1[ox1];
-                packed |= ((c0y * h0 + c1y * h1 + 32768u) >> 16) << (8 * i);
+        for (int r = 0; r < PYR_ROWS; r++) {
+            if (y0 + r >= L.h) break;
+            const int oy = (int)(cyv[r] & 0xFFFF);
+            const uint8_t* r0 = sp + (long)oy * spitch;
+            const uint8_t* r1 = sp + (long)min(oy + 1, sh - 1) * spitch;
+            const uint32_t c1y = cyv[r] >> 16, c0y = 256 - c1y;
+            uint32_t packed = 0;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                if (i < nvalid) {
+                    const int ox = (int)(cx[i] & 0xFFFF), ox1 = min(ox + 1, sw - 1);
+                    const uint32_t c1 = cx[i] >> 16, c0 = 256 - c1;
+                    const uint32_t h0 = c0 * r0[ox] + c1 * r0[ox1], h1 = c0 * r1[ox] + c1 * r1[ox1];
+                    packed |= ((c0y * h0 + c1y * h1 + 32768u) >> 16) << (8 * i);
+                }
             }
+            *reinterpret_cast<uint32_t*>(dp + (long)r * L.pitch) = packed;
         }
     }
-    uint8_t* dp = pyr + (long)f * g->pyr_frame + L.pyr_ofs + (long)y * L.pitch + x4;
-    *reinterpret_cast<uint32_t*>(dp) = packed;
 }
 
 // ------------------------------------------------------------------ FAST-9/16
@@ -1154,7 +1171,7 @@ int vo_launch_detect(vo_ctx* c, const FrameSrc& src, int F, hipStream_t st) {
 
     for (int l = 1; l < g.nlevels; l++) {
         const LevelGeom& L = g.lv[l];
-        dim3 grid((L.w + 255) / 256, (L.h + 3) / 4, F);   // plain order: the XCD-contiguous order measured 7 % slower here (no inter-block reuse)
+        dim3 grid((L.w + 255) / 256, (L.h + 4 * PYR_ROWS - 1) / (4 * PYR_ROWS), F);   // plain order: the XCD-contiguous order measured 7 % slower here (no inter-block reuse)
         KT(c, st, VO_K_PYRAMID, hipLaunchKernelGGL(k_pyramid, grid, dim3(256), 0, st, dg, src, pyr, (const ResizeCoef*)c->d_rtab.p, l));
     }
     if (g.ntiles > 0) {
