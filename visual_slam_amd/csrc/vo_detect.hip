@@ -535,11 +535,13 @@ __global__ __launch_bounds__(64) void k_fast_emit(const Geom* __restrict__ g, co
 // ------------------------------------------------------------------ retainBest
 // Sequential pieces of libstdc++ (bits/stl_algo.h, bits/stl_heap.h) on (key, payload) pairs;
 // comp(a, b) = key[a] > key[b].  Executed by one lane.
-__device__ inline void sel_swap(float* key, uint32_t* pay, int i, int j) {
+template <typename PT>
+__device__ inline void sel_swap(float* key, PT* pay, int i, int j) {
     float k = key[i]; key[i] = key[j]; key[j] = k;
-    uint32_t p = pay[i]; pay[i] = pay[j]; pay[j] = p;
+    PT p = pay[i]; pay[i] = pay[j]; pay[j] = p;
 }
-__device__ inline void sel_median_to_first(float* key, uint32_t* pay, int result, int a, int b, int c) {
+template <typename PT>
+__device__ inline void sel_median_to_first(float* key, PT* pay, int result, int a, int b, int c) {
     float ka = key[a], kb = key[b], kc = key[c];
     if (ka > kb) {
         if (kb > kc) sel_swap(key, pay, result, b);
@@ -549,11 +551,13 @@ __device__ inline void sel_median_to_first(float* key, uint32_t* pay, int result
     else if (kb > kc) sel_swap(key, pay, result, c);
     else sel_swap(key, pay, result, b);
 }
-__device__ inline void sel_insertion_sort(float* key, uint32_t* pay, int first, int last) {
+template <typename PT>
+__device__ inline void sel_insertion_sort(float* key, PT* pay, int first, int last) {
     for (int i = first + 1; i < last; i++)
         for (int j = i; j > first && key[j] > key[j - 1]; j--) sel_swap(key, pay, j, j - 1);
 }
-__device__ inline void sel_adjust_heap(float* key, uint32_t* pay, int first, int hole, int len, float vk, uint32_t vp) {
+template <typename PT>
+__device__ inline void sel_adjust_heap(float* key, PT* pay, int first, int hole, int len, float vk, PT vp) {
     const int top = hole;
     int child = hole;
     while (child < (len - 1) / 2) {
@@ -575,7 +579,8 @@ __device__ inline void sel_adjust_heap(float* key, uint32_t* pay, int first, int
     }
     key[first + hole] = vk; pay[first + hole] = vp;
 }
-__device__ inline void sel_heap_select(float* key, uint32_t* pay, int first, int nth, int last) {
+template <typename PT>
+__device__ inline void sel_heap_select(float* key, PT* pay, int first, int nth, int last) {
     const int middle = nth + 1, len = middle - first;
     if (len >= 2) {
         for (int parent = (len - 2) / 2;; parent--) {
@@ -585,7 +590,7 @@ __device__ inline void sel_heap_select(float* key, uint32_t* pay, int first, int
     }
     for (int i = middle; i < last; i++)
         if (key[i] > key[first]) {
-            float vk = key[i]; uint32_t vp = pay[i];
+            float vk = key[i]; PT vp = pay[i];
             key[i] = key[first]; pay[i] = pay[first];
             sel_adjust_heap(key, pay, first, 0, len, vk, vp);
         }
@@ -597,8 +602,8 @@ __device__ inline void sel_heap_select(float* key, uint32_t* pay, int first, int
 //         returns the cut.
 // MODE 1: std::partition with pred k >= p: left stoppers !(k >= p), right stoppers (k >= p);
 //         returns the number of elements satisfying pred.
-template <int NT, int MODE>
-__device__ int sel_partition(float* key, uint32_t* pay, uint32_t* lpos, uint32_t* rpos, int lo, int hi, float p, int* s_wl, int* s_wr, int* s_K) {
+template <int NT, int MODE, typename PT, typename QT>
+__device__ int sel_partition(float* key, PT* pay, QT* lpos, QT* rpos, int lo, int hi, float p, int* s_wl, int* s_wr, int* s_K) {
     constexpr int NW = NT / 64;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int len = hi - lo;
@@ -632,8 +637,8 @@ __device__ int sel_partition(float* key, uint32_t* pay, uint32_t* lpos, uint32_t
         bool isL = in && (MODE == 0 ? !(k > p) : !(k >= p));
         bool isR = in && (MODE == 0 ? !(p > k) : (k >= p));
         unsigned long long mL = __ballot(isL), mR = __ballot(isR);
-        if (isL) lpos[rl + __popcll(mL & lt)] = (uint32_t)i;
-        if (isR) rpos[totR - 1 - (rr + __popcll(mR & lt))] = (uint32_t)i;
+        if (isL) lpos[rl + __popcll(mL & lt)] = (QT)(i - lo);
+        if (isR) rpos[totR - 1 - (rr + __popcll(mR & lt))] = (QT)(i - lo);
         rl += __popcll(mL);
         rr += __popcll(mR);
     }
@@ -646,13 +651,13 @@ __device__ int sel_partition(float* key, uint32_t* pay, uint32_t* lpos, uint32_t
     if (lane == 0 && ck) atomicAdd(s_K, ck);
     __syncthreads();
     const int K = *s_K;
-    for (int k = tid; k < K; k += NT) sel_swap(key, pay, (int)lpos[k], (int)rpos[k]);
+    for (int k = tid; k < K; k += NT) sel_swap(key, pay, lo + (int)lpos[k], lo + (int)rpos[k]);
     int ret;
     if (MODE == 0) {
-        if (K == 0) ret = (int)lpos[0];
+        if (K == 0) ret = lo + (int)lpos[0];
         else {
-            ret = (int)rpos[K - 1];
-            if (K < totL) ret = min(ret, (int)lpos[K]);
+            ret = lo + (int)rpos[K - 1];
+            if (K < totL) ret = min(ret, lo + (int)lpos[K]);
         }
     } else {
         ret = totR;
@@ -662,15 +667,14 @@ __device__ int sel_partition(float* key, uint32_t* pay, uint32_t* lpos, uint32_t
 }
 
 // KeyPointsFilter::retainBest(list, mult*quota) for every (frame, level) list of the chunk.
-// The replay is a chain of ~log2(n) partitions, each a handful of dependent passes over the list, so
-// it is bound by memory latency: lists of up to CAP candidates are therefore copied to LDS, permuted
-// there (same code through generic pointers) and only the kept prefix is written back; longer lists
-// run in place in global memory.  Measured: the second retainBest (lists <= 2*quota, CAP 2048 = 32 KB, five
-// workgroups per CU) drops from 0.056 to 0.042 ms; for the first one (up to ~6000 FAST candidates per
-// level) the 64-128 KB of LDS cut residency to one or two workgroups per CU and the launch got SLOWER
-// (0.12 -> 0.17-0.19 ms), so it stays in global memory (CAP 64).
-template <int NT>
-__device__ int retain_best(float* key, uint32_t* pay, uint32_t* lpos, uint32_t* rpos, int n, int np, int* s_wl, int* s_wr, int* s_K) {
+// The replay is a chain of ~log2(n) partitions, each a handful of dependent passes over the list.  Lists of up
+// to CAP candidates are copied to LDS (keys + a 16-bit permutation), permuted there by the same code and only the
+// kept prefix is written back; longer lists run in place in global memory.  Measured per 64-frame launch: the
+// second retainBest (lists <= 2*quota, CAP 2048 = 20 KB) drops from 0.056 to 0.041 ms; the first one (up to
+// ~6000 FAST candidates per level) is NOT faster from LDS (CAP 8192 = 80 KB, two workgroups per CU: 0.104 ms
+// against 0.092 ms in global memory, and worse with more frames per launch), so it keeps CAP 64.
+template <int NT, typename PT, typename QT>
+__device__ int retain_best(float* key, PT* pay, QT* lpos, QT* rpos, int n, int np, int* s_wl, int* s_wr, int* s_K) {
     const int tid = threadIdx.x;
     int first = 0, last = n;
     const int nth = np - 1;
@@ -698,12 +702,16 @@ __device__ int retain_best(float* key, uint32_t* pay, uint32_t* lpos, uint32_t* 
     return np + totT;
 }
 
+// LDS layout for lists of up to CAP <= 65536 candidates: keys (4 B), the permutation as 16-bit original indices
+// and 16-bit stopper positions (relative to the partition range): 10 B per candidate, so CAP 8192 = 80 KB and two
+// workgroups fit a CU.  The payloads are gathered through the permutation at the end (staged in the stopper arrays).
 template <int NT, int CAP>
 __global__ __launch_bounds__(NT) void k_select(const Geom* __restrict__ g, float* key, uint32_t* pay, uint32_t* lpos, uint32_t* rpos,
                                                const int* __restrict__ cnt_in, int* __restrict__ cnt_out, int mult) {
     __shared__ int s_wl[NT / 64], s_wr[NT / 64], s_K;
     __shared__ float l_key[CAP];
-    __shared__ uint32_t l_pay[CAP], l_lpos[CAP], l_rpos[CAP];
+    __shared__ uint16_t l_idx[CAP];
+    __shared__ __attribute__((aligned(4))) uint16_t l_pos[2 * CAP];
     const int l = blockIdx.x, f = blockIdx.y, tid = threadIdx.x;
     const LevelGeom& L = g->lv[l];
     const long base = (long)f * g->cand_frame + L.cand_ofs;
@@ -720,10 +728,13 @@ __global__ __launch_bounds__(NT) void k_select(const Geom* __restrict__ g, float
     }
     int kept;
     if (n <= CAP) {
-        for (int i = tid; i < n; i += NT) { l_key[i] = key[i]; l_pay[i] = pay[i]; }
+        for (int i = tid; i < n; i += NT) { l_key[i] = key[i]; l_idx[i] = (uint16_t)i; }
         __syncthreads();
-        kept = retain_best<NT>(l_key, l_pay, l_lpos, l_rpos, n, np, s_wl, s_wr, &s_K);
-        for (int i = tid; i < kept; i += NT) { key[i] = l_key[i]; pay[i] = l_pay[i]; }
+        kept = retain_best<NT>(l_key, l_idx, l_pos, l_pos + CAP, n, np, s_wl, s_wr, &s_K);
+        uint32_t* stage = reinterpret_cast<uint32_t*>(l_pos);       // kept <= n <= CAP dwords
+        for (int i = tid; i < kept; i += NT) stage[i] = pay[l_idx[i]];
+        __syncthreads();
+        for (int i = tid; i < kept; i += NT) { key[i] = l_key[i]; pay[i] = stage[i]; }
     } else {
         kept = retain_best<NT>(key, pay, lpos, rpos, n, np, s_wl, s_wr, &s_K);
     }
