@@ -316,22 +316,35 @@ __global__ __launch_bounds__(256) void k_fast_tiles(const Geom* __restrict__ g, 
     if (tid < 252) {
         const int r0 = tid / 18, k = tid - r0 * 18;
         const int x = xa + 4 * k;
-        const bool whole = x + 3 < Lw;
+        if (xa + 72 <= Lw && y0 - 4 + PXR <= Lh) {
+            // interior tile (workgroup-uniform): no clamping, one address and two strides
+            const uint8_t* p = img + (long)(y0 - 4 + r0) * pitch + x;
+            uint32_t* q = reinterpret_cast<uint32_t*>(&px[r0 * PXP + 4 * k]);
+            uint32_t v0, v1, v2 = 0;
+            __builtin_memcpy(&v0, p, 4);                       // level 0 rows may be unaligned (caller's stride)
+            __builtin_memcpy(&v1, p + 14L * pitch, 4);
+            if (r0 + 28 < PXR) __builtin_memcpy(&v2, p + 28L * pitch, 4);
+            q[0] = v0;
+            q[14 * PXP / 4] = v1;
+            if (r0 + 28 < PXR) q[28 * PXP / 4] = v2;
+        } else {
+            const bool whole = x + 3 < Lw;
 #pragma unroll
-        for (int pass = 0; pass < 3; pass++) {
-            const int r = r0 + 14 * pass;
-            if (r < PXR) {
-                const int y = min(y0 - 4 + r, Lh - 1);
-                const uint8_t* rp = img + (long)y * pitch;
-                uint32_t v;
-                if (whole) {
-                    __builtin_memcpy(&v, rp + x, 4);  // level 0 rows may be unaligned (caller's stride)
-                } else {
-                    v = 0;
+            for (int pass = 0; pass < 3; pass++) {
+                const int r = r0 + 14 * pass;
+                if (r < PXR) {
+                    const int y = min(y0 - 4 + r, Lh - 1);
+                    const uint8_t* rp = img + (long)y * pitch;
+                    uint32_t v;
+                    if (whole) {
+                        __builtin_memcpy(&v, rp + x, 4);
+                    } else {
+                        v = 0;
 #pragma unroll
-                    for (int j = 0; j < 4; j++) v |= (uint32_t)rp[min(x + j, Lw - 1)] << (8 * j);
+                        for (int j = 0; j < 4; j++) v |= (uint32_t)rp[min(x + j, Lw - 1)] << (8 * j);
+                    }
+                    *reinterpret_cast<uint32_t*>(&px[r * PXP + 4 * k]) = v;
                 }
-                *reinterpret_cast<uint32_t*>(&px[r * PXP + 4 * k]) = v;
             }
         }
     }
