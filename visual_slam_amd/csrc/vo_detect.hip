@@ -679,6 +679,88 @@ __device__ int sel_partition(float* key, PT* pay, QT* lpos, QT* rpos, int lo, in
     return ret;
 }
 
+// The tail of introselect on a range of at most 64 elements, by ONE wavefront with the elements in registers
+// (lane i = position first + i): every remaining median-of-3 + Hoare partition step is shuffles, ballots and a
+// 64-entry LDS table of stopper positions -- no barriers and no memory round trips, where the block-wide steps
+// spend ~7 us each regardless of the range length.  Same closed form as sel_partition.  Returns false if the
+// depth limit was hit (the caller then runs the heap-select fallback on memory).
+template <typename PT>
+__device__ bool sel_small_wave(float* key, PT* pay, int& first, int& last, int nth, int& depth, int* tabL, int* tabR) {
+    const int lane = threadIdx.x & 63;
+    const int base = first, len = last - first;
+    float k = lane < len ? key[base + lane] : 0.f;
+    PT p = lane < len ? pay[base + lane] : (PT)0;
+    int lo = 0, hi = len;
+    const int nthr = nth - base;
+    const unsigned long long below = (1ull << lane) - 1ull, above = lane == 63 ? 0ull : ~((2ull << lane) - 1ull);
+    bool ok = true;
+    while (hi - lo > 3) {
+        if (depth == 0) { ok = false; break; }
+        --depth;
+        // __move_median_to_first(result = lo, a = lo+1, b = lo + (hi-lo)/2, c = hi-1)
+        const int a = lo + 1, b = lo + (hi - lo) / 2, c = hi - 1;
+        const float ka = __shfl(k, a), kb = __shfl(k, b), kc = __shfl(k, c);
+        int m;
+        if (ka > kb) m = (kb > kc) ? b : ((ka > kc) ? c : a);
+        else m = (ka > kc) ? a : ((kb > kc) ? c : b);
+        {
+            const float k_lo = __shfl(k, lo), k_m = __shfl(k, m);
+            const PT p_lo = __shfl(p, lo), p_m = __shfl(p, m);
+            if (lane == lo) { k = k_m; p = p_m; }
+            else if (lane == m) { k = k_lo; p = p_lo; }
+        }
+        const float pv = __shfl(k, lo);
+        // __unguarded_partition over [lo+1, hi)
+        const bool in = lane >= lo + 1 && lane < hi;
+        const bool isL = in && !(k > pv), isR = in && !(pv > k);
+        const unsigned long long mL = __ballot(isL), mR = __ballot(isR);
+        const int totL = (int)__popcll(mL), totR = (int)__popcll(mR);
+        const int rankL = (int)__popcll(mL & below), rankR = (int)__popcll(mR & above);
+        if (isL) tabL[rankL] = lane;       // ascending positions
+        if (isR) tabR[rankR] = lane;       // descending positions
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const int mn = min(totL, totR);
+        const bool cpair = lane < mn && tabL[lane] < tabR[lane];
+        const int K = (int)__popcll(__ballot(cpair));
+        int partner = -1;
+        if (isL && rankL < K) partner = tabR[rankL];
+        else if (isR && rankR < K) partner = tabL[rankR];
+        const float k2 = __shfl(k, partner < 0 ? lane : partner);
+        const PT p2 = __shfl(p, partner < 0 ? lane : partner);
+        if (partner >= 0) { k = k2; p = p2; }
+        int cut;
+        if (K == 0) cut = tabL[0];
+        else {
+            cut = tabR[K - 1];
+            if (K < totL) cut = min(cut, tabL[K]);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (cut <= nthr) lo = cut;
+        else hi = cut;
+    }
+    if (ok) {
+        // __insertion_sort of the <= 3 survivors, replayed on wave-uniform copies
+        const int cnt = hi - lo;
+        float e[3]; PT q[3];
+#pragma unroll
+        for (int t = 0; t < 3; t++) { e[t] = __shfl(k, min(lo + t, 63)); q[t] = __shfl(p, min(lo + t, 63)); }
+        for (int i = 1; i < cnt; i++)
+            for (int j = i; j > 0 && e[j] > e[j - 1]; j--) {
+                const float te = e[j]; e[j] = e[j - 1]; e[j - 1] = te;
+                const PT tq = q[j]; q[j] = q[j - 1]; q[j - 1] = tq;
+            }
+#pragma unroll
+        for (int t = 0; t < 3; t++)
+            if (t < cnt && lane == lo + t) { k = e[t]; p = q[t]; }
+    }
+    if (lane < len) { key[base + lane] = k; pay[base + lane] = p; }
+    first = base + lo;
+    last = base + hi;
+    return ok;
+}
+
 // KeyPointsFilter::retainBest(list, mult*quota) for every (frame, level) list of the chunk.
 // The replay is a chain of ~log2(n) partitions, each a handful of dependent passes over the list.  Lists of up
 // to CAP candidates are copied to LDS (keys + a 16-bit permutation), permuted there by the same code and only the
@@ -687,13 +769,27 @@ __device__ int sel_partition(float* key, PT* pay, QT* lpos, QT* rpos, int lo, in
 // ~6000 FAST candidates per level) is NOT faster from LDS (CAP 8192 = 80 KB, two workgroups per CU: 0.104 ms
 // against 0.092 ms in global memory, and worse with more frames per launch), so it keeps CAP 64.
 template <int NT, typename PT, typename QT>
-__device__ int retain_best(float* key, PT* pay, QT* lpos, QT* rpos, int n, int np, int* s_wl, int* s_wr, int* s_K) {
+__device__ int retain_best(float* key, PT* pay, QT* lpos, QT* rpos, int n, int np, int* s_wl, int* s_wr, int* s_K, int* tabL, int* tabR) {
     const int tid = threadIdx.x;
     int first = 0, last = n;
     const int nth = np - 1;
     int depth = 2 * (31 - __clz(n));
-    bool heap_done = false;
+    bool heap_done = false, sorted = false;
     while (last - first > 3) {
+        if (last - first <= 64) {
+            // every wavefront replays the tail redundantly on its own registers would race on memory: wavefront 0 does it,
+            // the range bookkeeping (first, last, depth) is recomputed identically by all from what it leaves in LDS
+            if (tid < 64) {
+                const bool ok = sel_small_wave(key, pay, first, last, nth, depth, tabL, tabR);
+                if (tid == 0) { s_wl[0] = first; s_wl[1] = last; s_wl[2] = depth; s_wl[3] = ok ? 1 : 0; }
+            }
+            __syncthreads();
+            first = s_wl[0]; last = s_wl[1]; depth = s_wl[2];
+            const bool ok = s_wl[3] != 0;
+            __syncthreads();
+            if (ok) { sorted = true; break; }
+            // depth limit inside the tail: fall through to the heap-select branch below
+        }
         if (depth == 0) {
             if (tid == 0) sel_heap_select(key, pay, first, nth, last);
             __syncthreads();
@@ -708,7 +804,7 @@ __device__ int retain_best(float* key, PT* pay, QT* lpos, QT* rpos, int n, int n
         if (cut <= nth) first = cut;
         else last = cut;
     }
-    if (!heap_done && tid == 0) sel_insertion_sort(key, pay, first, last);
+    if (!heap_done && !sorted && tid == 0) sel_insertion_sort(key, pay, first, last);
     __syncthreads();
     const float amb = key[np - 1];
     const int totT = sel_partition<NT, 1>(key, pay, lpos, rpos, np, n, amb, s_wl, s_wr, s_K);
@@ -721,7 +817,7 @@ __device__ int retain_best(float* key, PT* pay, QT* lpos, QT* rpos, int n, int n
 template <int NT, int CAP>
 __global__ __launch_bounds__(NT) void k_select(const Geom* __restrict__ g, float* key, uint32_t* pay, uint32_t* lpos, uint32_t* rpos,
                                                const int* __restrict__ cnt_in, int* __restrict__ cnt_out, int mult) {
-    __shared__ int s_wl[NT / 64], s_wr[NT / 64], s_K;
+    __shared__ int s_wl[NT / 64 < 4 ? 4 : NT / 64], s_wr[NT / 64], s_K, s_tabL[64], s_tabR[64];
     __shared__ float l_key[CAP];
     __shared__ uint16_t l_idx[CAP];
     __shared__ __attribute__((aligned(4))) uint16_t l_pos[2 * CAP];
@@ -743,13 +839,13 @@ __global__ __launch_bounds__(NT) void k_select(const Geom* __restrict__ g, float
     if (n <= CAP) {
         for (int i = tid; i < n; i += NT) { l_key[i] = key[i]; l_idx[i] = (uint16_t)i; }
         __syncthreads();
-        kept = retain_best<NT>(l_key, l_idx, l_pos, l_pos + CAP, n, np, s_wl, s_wr, &s_K);
+        kept = retain_best<NT>(l_key, l_idx, l_pos, l_pos + CAP, n, np, s_wl, s_wr, &s_K, s_tabL, s_tabR);
         uint32_t* stage = reinterpret_cast<uint32_t*>(l_pos);       // kept <= n <= CAP dwords
         for (int i = tid; i < kept; i += NT) stage[i] = pay[l_idx[i]];
         __syncthreads();
         for (int i = tid; i < kept; i += NT) { key[i] = l_key[i]; pay[i] = stage[i]; }
     } else {
-        kept = retain_best<NT>(key, pay, lpos, rpos, n, np, s_wl, s_wr, &s_K);
+        kept = retain_best<NT>(key, pay, lpos, rpos, n, np, s_wl, s_wr, &s_K, s_tabL, s_tabR);
     }
     if (tid == 0) cnt_out[f * VO_MAX_LEVELS + l] = kept;
 }
