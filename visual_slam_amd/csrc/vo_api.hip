@@ -97,6 +97,9 @@ static int ctx_init(vo_ctx* c) {
     const vo_orb_params& p = c->params;
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    HIP_TRY(c, hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
+    HIP_TRY(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+    HIP_TRY(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
     c->kp_cap = p.nfeatures + 1024;
     const long F = c->max_frames, kc = c->kp_cap, MP = c->max_pairs, CP = c->chunk_pairs;
     // geometry-sized buffers: size them for the largest image with a dry geometry pass
@@ -202,6 +205,9 @@ void vo_ctx_destroy(vo_ctx* c) {
                       &c->d_vote, &c->d_pair_nkp, &c->d_raw, &c->d_tri};
     for (DevBuf* b : bufs) dev_free(*b);
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }

@@ -1294,6 +1294,18 @@ int vo_launch_detect(vo_ctx* c, const FrameSrc& src, int F, hipStream_t st) {
         dim3 grid((L.w + 255) / 256, (L.h + 4 * PYR_ROWS - 1) / (4 * PYR_ROWS), F);   // plain order: the XCD-contiguous order measured 7 % slower here (no inter-block reuse)
         KT(c, st, VO_K_PYRAMID, hipLaunchKernelGGL(k_pyramid, grid, dim3(256), 0, st, dg, src, pyr, (const ResizeCoef*)c->d_rtab.p, l));
     }
+    // The blur only needs the pyramid: outside the timing mode it runs on the context's second stream, next to the
+    // FAST -> retainBest -> Harris -> retainBest -> orientation chain (whose retainBest replays are latency bound and
+    // leave most of the chip idle), and joins before the descriptors.
+    BlurK bk;
+    gaussian_kernel7_sigma2(bk);
+    const bool fork_blur = !c->timing && c->debug_stop == 0 && c->aux_stream != nullptr;
+    if (fork_blur) {
+        HIP_TRY(c, hipEventRecord(c->ev_fork, st));
+        HIP_TRY(c, hipStreamWaitEvent(c->aux_stream, c->ev_fork, 0));
+        hipLaunchKernelGGL(k_blur, dim3(pad8(g.nbtiles * F)), dim3(256), 0, c->aux_stream, dg, src, pyr, blur, (const TileDesc*)c->d_btiles.p, bk, F);
+        HIP_TRY(c, hipEventRecord(c->ev_join, c->aux_stream));
+    }
     if (g.ntiles > 0) {
         static const int abl = getenv("VO_FAST_ABLATE") ? atoi(getenv("VO_FAST_ABLATE")) : 0;   // timing experiments only
         if (abl == 1) hipLaunchKernelGGL(k_fast_tiles<1>, dim3(pad8(g.ntiles * F)), dim3(256), 0, st, dg, src, pyr, tiles, (uint32_t*)c->d_tile_list.p, (uint8_t*)c->d_seg_cnt.p, F);
@@ -1317,9 +1329,8 @@ int vo_launch_detect(vo_ctx* c, const FrameSrc& src, int F, hipStream_t st) {
     KT(c, st, VO_K_SELECT2, hipLaunchKernelGGL((k_select<256, 2048>), dim3(g.nlevels, F), dim3(256), 0, st, dg, key, payload, (uint32_t*)c->d_lpos.p, (uint32_t*)c->d_rpos.p, cnt_sel1, cnt_sel2, 1));
     KT(c, st, VO_K_ORIENT, hipLaunchKernelGGL(k_orient, dim3(pad8(ORIENT_BX * g.nlevels * F)), dim3(256), 0, st, dg, src, pyr, cnt_sel2, key, payload, (vo_keypoint*)c->d_kp.p,
                        (uint32_t*)c->d_kplvl.p, (int*)c->d_nkp.p, (int*)c->d_frame_status.p, F));
-    BlurK bk;
-    gaussian_kernel7_sigma2(bk);
-    KT(c, st, VO_K_BLUR, hipLaunchKernelGGL(k_blur, dim3(pad8(g.nbtiles * F)), dim3(256), 0, st, dg, src, pyr, blur, (const TileDesc*)c->d_btiles.p, bk, F));
+    if (fork_blur) HIP_TRY(c, hipStreamWaitEvent(st, c->ev_join, 0));
+    else KT(c, st, VO_K_BLUR, hipLaunchKernelGGL(k_blur, dim3(pad8(g.nbtiles * F)), dim3(256), 0, st, dg, src, pyr, blur, (const TileDesc*)c->d_btiles.p, bk, F));
     const int rb_nbx = (g.kp_cap + RB_KPB - 1) / RB_KPB;
     KT(c, st, VO_K_RBRIEF, hipLaunchKernelGGL(k_rbrief, dim3(pad8(rb_nbx * F)), dim3(256), 0, st, dg, blur, (const signed char*)c->d_pat.p, (const int*)c->d_nkp.p,
                        (const vo_keypoint*)c->d_kp.p, (const uint32_t*)c->d_kplvl.p, (uint8_t*)c->d_desc.p, rb_nbx, F));

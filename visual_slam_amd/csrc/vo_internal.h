@@ -90,6 +90,8 @@ struct vo_ctx {
     vo_orb_params params;
     std::string err;
     hipStream_t stream = nullptr;  // own stream for the host-pointer entry points
+    hipStream_t aux_stream = nullptr;            // second stream: the blur runs beside the keypoint chain
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 
     // geometry currently built (w,h) and its device copies
     Geom geom;
