@@ -1320,7 +1320,7 @@ int vo_launch_detect(vo_ctx* c, const FrameSrc& src, int F, hipStream_t st) {
     }
     if (c->debug_stop == 1) { HIP_TRY(c, hipGetLastError()); return VO_OK; }
     // long candidate lists (4K frames: ~10^5 per level) are pass-bound, short ones barrier-bound
-    if (g.lv[0].cand_cap > 65536)
+    if ((long)g.w * g.h > 2000000L)
         KT(c, st, VO_K_SELECT1, hipLaunchKernelGGL((k_select<1024, 64>), dim3(g.nlevels, F), dim3(1024), 0, st, dg, key, payload, (uint32_t*)c->d_lpos.p, (uint32_t*)c->d_rpos.p, cnt_fast, cnt_sel1, 2));
     else
         KT(c, st, VO_K_SELECT1, hipLaunchKernelGGL((k_select<256, 64>), dim3(g.nlevels, F), dim3(256), 0, st, dg, key, payload, (uint32_t*)c->d_lpos.p, (uint32_t*)c->d_rpos.p, cnt_fast, cnt_sel1, 2));
