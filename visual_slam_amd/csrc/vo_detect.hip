@@ -1323,7 +1323,7 @@ int vo_launch_detect(vo_ctx* c, const FrameSrc& src, int F, hipStream_t st) {
     if ((long)g.w * g.h > 2000000L)
         KT(c, st, VO_K_SELECT1, hipLaunchKernelGGL((k_select<1024, 64>), dim3(g.nlevels, F), dim3(1024), 0, st, dg, key, payload, (uint32_t*)c->d_lpos.p, (uint32_t*)c->d_rpos.p, cnt_fast, cnt_sel1, 2));
     else
-        KT(c, st, VO_K_SELECT1, hipLaunchKernelGGL((k_select<256, 64>), dim3(g.nlevels, F), dim3(256), 0, st, dg, key, payload, (uint32_t*)c->d_lpos.p, (uint32_t*)c->d_rpos.p, cnt_fast, cnt_sel1, 2));
+        KT(c, st, VO_K_SELECT1, hipLaunchKernelGGL((k_select<256, 8000>), dim3(g.nlevels, F), dim3(256), 0, st, dg, key, payload, (uint32_t*)c->d_lpos.p, (uint32_t*)c->d_rpos.p, cnt_fast, cnt_sel1, 2));
     KT(c, st, VO_K_HARRIS, hipLaunchKernelGGL(k_harris, dim3(pad8(HARRIS_BX * g.nlevels * F)), dim3(256), 0, st, dg, src, pyr, cnt_sel1, key, payload, F));
     if (c->debug_stop == 2) { HIP_TRY(c, hipGetLastError()); return VO_OK; }
     KT(c, st, VO_K_SELECT2, hipLaunchKernelGGL((k_select<256, 2048>), dim3(g.nlevels, F), dim3(256), 0, st, dg, key, payload, (uint32_t*)c->d_lpos.p, (uint32_t*)c->d_rpos.p, cnt_sel1, cnt_sel2, 1));
