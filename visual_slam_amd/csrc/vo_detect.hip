@@ -615,6 +615,11 @@ __device__ inline void sel_heap_select(float* key, PT* pay, int first, int nth, 
 //         returns the cut.
 // MODE 1: std::partition with pred k >= p: left stoppers !(k >= p), right stoppers (k >= p);
 //         returns the number of elements satisfying pred.
+// With L the left stoppers in ascending and R the right stoppers in descending position order, the scan swaps the
+// pairs (L[k], R[k]) while L[k] < R[k]; L[k] - R[k] increases with k, so "L[k] < R[k]" holds exactly for k < K and
+// every pair can decide for itself.  One pass classifies and writes each wavefront's stoppers, in order, to the
+// wavefront's own segment of lpos/rpos (positions relative to lo); L[k] / R[k] are then looked up through the
+// per-wavefront counts.  Three barriers per partition.
 template <int NT, int MODE, typename PT, typename QT>
 __device__ int sel_partition(float* key, PT* pay, QT* lpos, QT* rpos, int lo, int hi, float p, int* s_wl, int* s_wr, int* s_K) {
     constexpr int NW = NT / 64;
@@ -622,55 +627,59 @@ __device__ int sel_partition(float* key, PT* pay, QT* lpos, QT* rpos, int lo, in
     const int len = hi - lo;
     const int chunk = (((len + NW - 1) / NW) + 63) & ~63;
     const int wlo = lo + w * chunk, whi = min(wlo + chunk, hi);
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    if (tid == 0) *s_K = 0;
     int cl = 0, cr = 0;
+    const int seg = w * chunk;
     for (int b = wlo; b < whi; b += 64) {
-        int i = b + lane;
-        bool in = i < whi;
-        float k = in ? key[i] : 0.f;
-        bool isL = in && (MODE == 0 ? !(k > p) : !(k >= p));
-        bool isR = in && (MODE == 0 ? !(p > k) : (k >= p));
-        cl += __popcll(__ballot(isL));
-        cr += __popcll(__ballot(isR));
+        const int i = b + lane;
+        const bool in = i < whi;
+        const float k = in ? key[i] : 0.f;
+        const bool isL = in && (MODE == 0 ? !(k > p) : !(k >= p));
+        const bool isR = in && (MODE == 0 ? !(p > k) : (k >= p));
+        const unsigned long long mL = __ballot(isL), mR = __ballot(isR);
+        if (isL) lpos[seg + cl + (int)__popcll(mL & lt)] = (QT)(i - lo);
+        if (isR) rpos[seg + cr + (int)__popcll(mR & lt)] = (QT)(i - lo);
+        cl += (int)__popcll(mL);
+        cr += (int)__popcll(mR);
     }
     if (lane == 0) { s_wl[w] = cl; s_wr[w] = cr; }
     __syncthreads();
-    if (tid == 0) *s_K = 0;
-    int baseL = 0, baseR = 0, totL = 0, totR = 0;
-    for (int w2 = 0; w2 < NW; w2++) {
-        int a = s_wl[w2], b = s_wr[w2];
-        if (w2 < w) { baseL += a; baseR += b; }
-        totL += a; totR += b;
-    }
-    const unsigned long long lt = (1ull << lane) - 1ull;
-    int rl = baseL, rr = baseR;
-    for (int b = wlo; b < whi; b += 64) {
-        int i = b + lane;
-        bool in = i < whi;
-        float k = in ? key[i] : 0.f;
-        bool isL = in && (MODE == 0 ? !(k > p) : !(k >= p));
-        bool isR = in && (MODE == 0 ? !(p > k) : (k >= p));
-        unsigned long long mL = __ballot(isL), mR = __ballot(isR);
-        if (isL) lpos[rl + __popcll(mL & lt)] = (QT)(i - lo);
-        if (isR) rpos[totR - 1 - (rr + __popcll(mR & lt))] = (QT)(i - lo);
-        rl += __popcll(mL);
-        rr += __popcll(mR);
-    }
-    __syncthreads();
+    int baseL[NW + 1], baseR[NW + 1];
+    baseL[0] = baseR[0] = 0;
+#pragma unroll
+    for (int w2 = 0; w2 < NW; w2++) { baseL[w2 + 1] = baseL[w2] + s_wl[w2]; baseR[w2 + 1] = baseR[w2] + s_wr[w2]; }
+    const int totL = baseL[NW], totR = baseR[NW];
+    auto Lat = [&](int k) -> int {          // k-th left stopper, ascending
+        int w2 = 0, bs = 0;
+#pragma unroll
+        for (int q = 1; q < NW; q++) { const bool ge = k >= baseL[q]; w2 += ge ? 1 : 0; bs = ge ? baseL[q] : bs; }
+        return (int)lpos[w2 * chunk + (k - bs)];
+    };
+    auto Rat = [&](int k) -> int {          // k-th right stopper, descending
+        const int j = totR - 1 - k;
+        int w2 = 0, bs = 0;
+#pragma unroll
+        for (int q = 1; q < NW; q++) { const bool ge = j >= baseR[q]; w2 += ge ? 1 : 0; bs = ge ? baseR[q] : bs; }
+        return (int)rpos[w2 * chunk + (j - bs)];
+    };
     const int m = min(totL, totR);
     int ck = 0;
-    for (int k = tid; k < m; k += NT) ck += (lpos[k] < rpos[k]) ? 1 : 0;
+    for (int k = tid; k < m; k += NT) {
+        const int a = Lat(k), b = Rat(k);
+        if (a < b) { sel_swap(key, pay, lo + a, lo + b); ck++; }
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) ck += __shfl_xor(ck, o);
     if (lane == 0 && ck) atomicAdd(s_K, ck);
     __syncthreads();
     const int K = *s_K;
-    for (int k = tid; k < K; k += NT) sel_swap(key, pay, lo + (int)lpos[k], lo + (int)rpos[k]);
     int ret;
     if (MODE == 0) {
-        if (K == 0) ret = lo + (int)lpos[0];
+        if (K == 0) ret = lo + Lat(0);
         else {
-            ret = lo + (int)rpos[K - 1];
-            if (K < totL) ret = min(ret, lo + (int)lpos[K]);
+            ret = lo + Rat(K - 1);
+            if (K < totL) ret = min(ret, lo + Lat(K));
         }
     } else {
         ret = totR;
@@ -762,12 +771,13 @@ __device__ bool sel_small_wave(float* key, PT* pay, int& first, int& last, int n
 }
 
 // KeyPointsFilter::retainBest(list, mult*quota) for every (frame, level) list of the chunk.
-// The replay is a chain of ~log2(n) partitions, each a handful of dependent passes over the list.  Lists of up
-// to CAP candidates are copied to LDS (keys + a 16-bit permutation), permuted there by the same code and only the
-// kept prefix is written back; longer lists run in place in global memory.  Measured per 64-frame launch: the
-// second retainBest (lists <= 2*quota, CAP 2048 = 20 KB) drops from 0.056 to 0.041 ms; the first one (up to
-// ~6000 FAST candidates per level) is NOT faster from LDS (CAP 8192 = 80 KB, two workgroups per CU: 0.104 ms
-// against 0.092 ms in global memory, and worse with more frames per launch), so it keeps CAP 64.
+// The replay is a chain of ~log2(n) partitions, each a few dependent passes over the list plus barriers, so it is
+// bound by latency, not throughput.  Lists of up to CAP candidates are copied to LDS (keys + a 16-bit permutation),
+// permuted there by the same code and only the kept prefix is written back; longer lists run in place in global
+// memory.  CAP is chosen so that TWO workgroups fit a CU (10 B per candidate: CAP 8000 = 80 KB for the first
+// retainBest, whose lists reach ~6000 FAST candidates per level; CAP 2048 for the second): with one workgroup per
+// CU the launch was slower than the global-memory version.  Per 64-frame launch: 0.089 -> 0.054 ms (first),
+// 0.056 -> 0.035 ms (second).
 template <int NT, typename PT, typename QT>
 __device__ int retain_best(float* key, PT* pay, QT* lpos, QT* rpos, int n, int np, int* s_wl, int* s_wr, int* s_K, int* tabL, int* tabR) {
     const int tid = threadIdx.x;
