@@ -187,12 +187,20 @@ __global__ __launch_bounds__(256) void k_pyramid(const Geom* __restrict__ g, Fra
 #pragma unroll
     for (int r = 0; r < PYR_ROWS; r++) cyv[r] = rt[L.ytab + min(y0 + r, L.h - 1)];
     if (olast + 1 - o0 < 8 && o0 + 8 <= sw) {
-        unsigned long long a[PYR_ROWS], b[PYR_ROWS];
+        uint2 a[PYR_ROWS], b[PYR_ROWS];
 #pragma unroll
         for (int r = 0; r < PYR_ROWS; r++) {
             const int oy = (int)(cyv[r] & 0xFFFF);
             __builtin_memcpy(&a[r], sp + (long)oy * spitch + o0, 8);
             __builtin_memcpy(&b[r], sp + (long)min(oy + 1, sh - 1) * spitch + o0, 8);
+        }
+        // v_perm_b32 selectors picking source bytes (rel, rel+1) of the 8 loaded ones -- the same for all rows of the lane
+        uint32_t sel[4], c1v[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const uint32_t rel = (cx[i] & 0xFFFF) - (uint32_t)o0;
+            sel[i] = 0x0C0C0100u + rel * 0x0101u;
+            c1v[i] = cx[i] >> 16;
         }
 #pragma unroll
         for (int r = 0; r < PYR_ROWS; r++) {
@@ -201,11 +209,9 @@ __global__ __launch_bounds__(256) void k_pyramid(const Geom* __restrict__ g, Fra
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 if (i < nvalid) {
-                    const int rel = (int)(cx[i] & 0xFFFF) - o0;
-                    const uint32_t c1 = cx[i] >> 16, c0 = 256 - c1;
-                    const uint32_t p00 = (uint32_t)(a[r] >> (8 * rel)) & 0xFF, p01 = (uint32_t)(a[r] >> (8 * rel + 8)) & 0xFF;
-                    const uint32_t p10 = (uint32_t)(b[r] >> (8 * rel)) & 0xFF, p11 = (uint32_t)(b[r] >> (8 * rel + 8)) & 0xFF;
-                    const uint32_t h0 = c0 * p00 + c1 * p01, h1 = c0 * p10 + c1 * p11;
+                    const uint32_t c1 = c1v[i], c0 = 256 - c1;
+                    const uint32_t pa = __builtin_amdgcn_perm(a[r].y, a[r].x, sel[i]), pb = __builtin_amdgcn_perm(b[r].y, b[r].x, sel[i]);
+                    const uint32_t h0 = c0 * (pa & 0xFF) + c1 * (pa >> 8), h1 = c0 * (pb & 0xFF) + c1 * (pb >> 8);
                     packed |= ((c0y * h0 + c1y * h1 + 32768u) >> 16) << (8 * i);
                 }
             }
