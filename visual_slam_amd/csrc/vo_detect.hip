@@ -1315,7 +1315,8 @@ int vo_launch_detect(vo_ctx* c, const FrameSrc& src, int F, hipStream_t st) {
     // leave most of the chip idle), and joins before the descriptors.
     BlurK bk;
     gaussian_kernel7_sigma2(bk);
-    const bool fork_blur = !c->timing && c->debug_stop == 0 && c->aux_stream != nullptr;
+    static const bool serial = getenv("VO_SERIAL") != nullptr;   // profiling aid: one kernel at a time, so trace durations are per kernel
+    const bool fork_blur = !serial && !c->timing && c->debug_stop == 0 && c->aux_stream != nullptr;
     if (fork_blur) {
         HIP_TRY(c, hipEventRecord(c->ev_fork, st));
         HIP_TRY(c, hipStreamWaitEvent(c->aux_stream, c->ev_fork, 0));
