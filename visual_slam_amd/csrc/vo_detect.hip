@@ -3,17 +3,19 @@
 // Stands behind orb.detectAndCompute(img, None) at /root/reference/libs/vo_utils.py:94-95
 // (OpenCV 4.8.0 ORB_Impl::detectAndCompute).  Stages, one launch each over
 // every frame of the chunk:
-//   k_pyramid (x7)  cascaded INTER_LINEAR_EXACT resize, 8.8 fixed point          [HBM bound]
-//   k_fast_tiles    FAST-9/16 + cornerScore + 3x3 NMS on 32x32 LDS tiles          [HBM bound]
+//   k_pyramid (x7)  cascaded INTER_LINEAR_EXACT resize, 8.8 fixed point (4 px x 4 rows per lane)
+//   k_fast_tiles    FAST-9/16 + cornerScore + 3x3 NMS on 60x30 LDS tiles: pretest -> polarity
+//                   queues -> arc scoring -> queue-driven NMS -> bitmap-rank compaction   [VALU bound]
 //   k_fast_scan     raster-order offsets of every (row, tile column) segment
 //   k_fast_emit     candidates to per-level lists in raster order
 //   k_select        KeyPointsFilter::retainBest: data-parallel replay of libstdc++
-//                   nth_element + partition (tests/introselect_model.py)
+//                   nth_element + partition (tests/introselect_model.py), lists in LDS
 //   k_harris        7x7 Harris response at the kept candidates
 //   k_select        second retainBest on the Harris response
-//   k_orient        intensity-centroid angle + final KeyPoint records
-//   k_blur          7x7 sigma=2 Gaussian of every level (sepFilter2D arithmetic)   [HBM bound]
-//   k_rbrief        rotated BRIEF-256, one wavefront per keypoint
+//   k_orient        intensity-centroid angle (v_sad_u8 / v_dot4_u32_u8 moments) + KeyPoint records
+//   k_blur          7x7 sigma=2 Gaussian of every level (sepFilter2D arithmetic), second stream
+//   k_rbrief        rotated BRIEF-256 from LDS-staged patches, one wavefront per keypoint
+// The per-frame gather/tile kernels use an XCD-contiguous block order (see xcd_block below).
 // All integer stages are bit exact by construction; float stages are compiled with
 // -ffp-contract=off and spell out fmaf where the CPU build of OpenCV contracts.
 #include <algorithm>
