@@ -22,7 +22,21 @@ __global__ __launch_bounds__(256) void k(uint32_t* out, uint32_t seed, int iters
             if (MODE == 10) acc[i] = (acc[i] << 3) + a[i];                 // lshl_add
             if (MODE == 11) acc[i] = ((acc[i] >> 4) & 0xF) + a[i];         // bfe + add
             if (MODE == 12) acc[i] = (acc[i] & a[i]) + 1;                  // and + add
+            if (MODE == 13) acc[i] = __float_as_uint(__fmaf_rn(__uint_as_float(a[i]), 1.0001f, __uint_as_float(acc[i])));   // v_fma_f32
+            if (MODE == 15) acc[i] = __builtin_amdgcn_perm(acc[i], a[i], 0x07020500u) + 1;   // v_perm + add
+            if (MODE == 16) acc[i] = __builtin_amdgcn_sad_u8(acc[i], a[i], 1u);              // v_sad_u8
+            if (MODE == 17) acc[i] = __builtin_amdgcn_udot4(acc[i], a[i], 1u, false);        // v_dot4_u32_u8
         }
+    }
+    if (MODE == 14) {   // v_pk_fma_f32: 4 packed fmas = 8 fp32 fmas per trip
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        f2 x[4], y[4];
+        for (int i = 0; i < 4; i++) { x[i] = f2{__uint_as_float(a[2 * i]), __uint_as_float(a[2 * i + 1])}; y[i] = f2{(float)i, 1.f}; }
+        const f2 m = f2{1.0001f, 0.9999f};
+        for (int it = 0; it < iters; it++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) y[i] = __builtin_elementwise_fma(x[i], m, y[i]);
+        for (int i = 0; i < 4; i++) { acc[2 * i] = __float_as_uint(y[i].x); acc[2 * i + 1] = __float_as_uint(y[i].y); }
     }
     uint32_t s = 0;
     for (int i = 0; i < 8; i++) s += acc[i];
@@ -63,5 +77,10 @@ int main(int argc, char** argv) {
     run<10>("lshl_add", 1);
     run<11>("bfe+add", 2);
     run<12>("and+add", 2);
+    run<13>("fma_f32", 1);
+    run<14>("pk_fma_f32", 1);
+    run<15>("perm+add", 2);
+    run<16>("sad_u8", 1);
+    run<17>("dot4_u8", 1);
     return 0;
 }

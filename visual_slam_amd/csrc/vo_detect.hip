@@ -1061,19 +1061,35 @@ __global__ __launch_bounds__(256) void k_blur(const Geom* __restrict__ g, FrameS
     int pitch;
     const uint8_t* img = level_ptr(g, src, pyr, f, td.level, pitch);
     const int x0 = td.tx * VO_BLUR_TW, y0 = td.ty * VO_BLUR_TH;
-    for (int i = tid; i < BL_ROWS * 18; i += 256) {
-        const int r = i / 18, k = i - r * 18;
-        const int y = reflect101c(y0 - 3 + r, L.h), x = x0 - 4 + 4 * k;
-        const uint8_t* rp = img + (long)y * pitch;
-        uint32_t v;
-        if (x >= 0 && x + 3 < L.w) {
-            __builtin_memcpy(&v, rp + x, 4);
-        } else {
-            v = 0;
-#pragma unroll
-            for (int j = 0; j < 4; j++) v |= (uint32_t)rp[reflect101c(x + j, L.w)] << (8 * j);
+    if (x0 - 4 >= 0 && x0 + 68 <= L.w && y0 - 3 >= 0 && y0 - 3 + BL_ROWS <= L.h) {
+        // interior tile (workgroup-uniform): no reflection, one address and two strides per lane (252 lanes x 14 rows x 3)
+        if (tid < 252) {
+            const int r0 = tid / 18, k = tid - r0 * 18;
+            const uint8_t* p = img + (long)(y0 - 3 + r0) * pitch + (x0 - 4 + 4 * k);
+            uint32_t* q = reinterpret_cast<uint32_t*>(&sp[r0 * BL_SP + 4 * k]);
+            uint32_t v0, v1, v2 = 0;
+            __builtin_memcpy(&v0, p, 4);
+            __builtin_memcpy(&v1, p + 14L * pitch, 4);
+            if (r0 + 28 < BL_ROWS) __builtin_memcpy(&v2, p + 28L * pitch, 4);
+            q[0] = v0;
+            q[14 * BL_SP / 4] = v1;
+            if (r0 + 28 < BL_ROWS) q[28 * BL_SP / 4] = v2;
         }
-        *reinterpret_cast<uint32_t*>(&sp[r * BL_SP + 4 * k]) = v;
+    } else {
+        for (int i = tid; i < BL_ROWS * 18; i += 256) {
+            const int r = i / 18, k = i - r * 18;
+            const int y = reflect101c(y0 - 3 + r, L.h), x = x0 - 4 + 4 * k;
+            const uint8_t* rp = img + (long)y * pitch;
+            uint32_t v;
+            if (x >= 0 && x + 3 < L.w) {
+                __builtin_memcpy(&v, rp + x, 4);
+            } else {
+                v = 0;
+#pragma unroll
+                for (int j = 0; j < 4; j++) v |= (uint32_t)rp[reflect101c(x + j, L.w)] << (8 * j);
+            }
+            *reinterpret_cast<uint32_t*>(&sp[r * BL_SP + 4 * k]) = v;
+        }
     }
     __syncthreads();
     const bool use_fma = g->fma != 0;
