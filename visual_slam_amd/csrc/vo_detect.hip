@@ -296,7 +296,6 @@ __device__ __forceinline__ int lanes_below(unsigned long long m) {
 }
 
 #define FQ_CAP 4096
-template <int ABL>
 __global__ __launch_bounds__(256) void k_fast_tiles(const Geom* __restrict__ g, FrameSrc src, const uint8_t* __restrict__ pyr,
                                                     const TileDesc* __restrict__ tiles, uint32_t* __restrict__ tile_list,
                                                     uint8_t* __restrict__ seg_cnt, int nframes) {
@@ -358,7 +357,6 @@ __global__ __launch_bounds__(256) void k_fast_tiles(const Geom* __restrict__ g, 
     }
     __syncthreads();
     const int thr = g->fast_threshold;
-    if (ABL == 3) return;
     // Stage 1: every score position (64 x 32), 4 adjacent positions per lane and iteration, read as
     // aligned LDS dwords.  Score column c <-> LDS column c+6, score row r <-> LDS row r+3.
     // A 9-arc contains one pixel of every opposite pair, so with the four even pairs
@@ -368,7 +366,7 @@ __global__ __launch_bounds__(256) void k_fast_tiles(const Geom* __restrict__ g, 
     const int cmax = min(VO_TILE_W + 2, Lw - 3 - (x0 - 1));   // FAST is defined 3 px inside the level
     const int rmax = Lh - 3 - (y0 - 1);
 #pragma unroll
-    for (int it = 0; it < (ABL == 2 ? 0 : 2); it++) {
+    for (int it = 0; it < 2; it++) {
         const int run = tid + 256 * it;          // 16 runs per row
         const int r = run >> 4, k4 = (run & 15) * 4;
         const uint32_t* rowC = reinterpret_cast<const uint32_t*>(&px[(r + 3) * PXP + k4]);
@@ -412,7 +410,7 @@ __global__ __launch_bounds__(256) void k_fast_tiles(const Geom* __restrict__ g, 
     __syncthreads();
     // Stage 2: arc extremes + cornerScore of the queued positions.  A position in both queues (an edge
     // through the centre) takes the larger of its two scores: the darker pass runs after a barrier.
-    const int nb = ABL == 1 ? 0 : (qcnt & 0xFFFF), nd = ABL == 1 ? 0 : (qcnt >> 16);
+    const int nb = qcnt & 0xFFFF, nd = qcnt >> 16;
     for (int q = tid; q < nb; q += 256) {
         const int i = queue[q];
         const int r = i >> 6, c = i & 63;
@@ -1342,11 +1340,7 @@ int vo_launch_detect(vo_ctx* c, const FrameSrc& src, int F, hipStream_t st) {
         HIP_TRY(c, hipEventRecord(c->ev_join, c->aux_stream));
     }
     if (g.ntiles > 0) {
-        static const int abl = getenv("VO_FAST_ABLATE") ? atoi(getenv("VO_FAST_ABLATE")) : 0;   // timing experiments only
-        if (abl == 1) hipLaunchKernelGGL(k_fast_tiles<1>, dim3(pad8(g.ntiles * F)), dim3(256), 0, st, dg, src, pyr, tiles, (uint32_t*)c->d_tile_list.p, (uint8_t*)c->d_seg_cnt.p, F);
-        if (abl == 2) hipLaunchKernelGGL(k_fast_tiles<2>, dim3(pad8(g.ntiles * F)), dim3(256), 0, st, dg, src, pyr, tiles, (uint32_t*)c->d_tile_list.p, (uint8_t*)c->d_seg_cnt.p, F);
-        if (abl == 3) hipLaunchKernelGGL(k_fast_tiles<3>, dim3(pad8(g.ntiles * F)), dim3(256), 0, st, dg, src, pyr, tiles, (uint32_t*)c->d_tile_list.p, (uint8_t*)c->d_seg_cnt.p, F);
-        KT(c, st, VO_K_FAST_TILES, hipLaunchKernelGGL(k_fast_tiles<0>, dim3(pad8(g.ntiles * F)), dim3(256), 0, st, dg, src, pyr, tiles, (uint32_t*)c->d_tile_list.p, (uint8_t*)c->d_seg_cnt.p, F));
+        KT(c, st, VO_K_FAST_TILES, hipLaunchKernelGGL(k_fast_tiles, dim3(pad8(g.ntiles * F)), dim3(256), 0, st, dg, src, pyr, tiles, (uint32_t*)c->d_tile_list.p, (uint8_t*)c->d_seg_cnt.p, F));
     }
     KT(c, st, VO_K_FAST_SCAN, hipLaunchKernelGGL(k_fast_scan, dim3(g.nlevels, F), dim3(256), 0, st, dg, (const uint8_t*)c->d_seg_cnt.p, (uint32_t*)c->d_seg_ofs.p, cnt_fast));
     if (g.ntiles > 0) {
