@@ -210,3 +210,39 @@ def test_config4_4k_20k_features(oracle):
     assert rc == 0 and res["status"] == 0
     assert [res["n_kp1"], res["n_kp2"], res["n_match"], res["n_inlier"]] == counts.tolist()
     assert rot_angle(T[:3, :3], res["T"][:3, :3]) < 1e-6 and dir_angle(T[:3, 3], res["T"][:3, 3]) < 1e-6
+
+
+def test_batching_is_invisible(K02):
+    """Size-independent properties on a ragged batch: results do not depend on chunk_pairs / max_pairs, repeated pairs
+    give identical records (determinism), and two contexts driven from two host threads agree with one."""
+    import torch
+    from concurrent.futures import ThreadPoolExecutor
+    from visual_slam_amd import _lib, synth
+    a, b = synth.make_batch(range(6), workers=1)
+    reps = 7                                             # 42 pairs: not a multiple of any chunk size below
+    A = np.concatenate([a] * reps); B = np.concatenate([b] * reps)
+    n, h, w = A.shape
+    K = synth.K_KITTI02
+    dA = torch.from_numpy(A).cuda(); dB = torch.from_numpy(B).cuda()
+
+    def run(chunk, maxp, lo=0, hi=n):
+        c = _lib.Context(max_w=w, max_h=h, chunk_pairs=chunk, max_pairs=maxp)
+        try:
+            return c.pairs_run_device(dA.data_ptr() + lo * h * w, dB.data_ptr() + lo * h * w, hi - lo, w, h, w, K)
+        finally:
+            c.close()
+
+    ref = run(8, n)
+    assert (ref["status"] == 0).all()
+    for f in ref.dtype.names:                            # determinism: the 7 repetitions are identical
+        v = ref[f].reshape(reps, 6, *ref[f].shape[1:])
+        assert all(np.array_equal(v[0], v[r]) for r in range(1, reps)), f
+    for chunk, maxp in ((5, 16), (32, 42), (1, 3)):
+        got = run(chunk, maxp, 0, 18 if chunk == 1 else n)
+        for f in ref.dtype.names:
+            assert np.array_equal(got[f], ref[f][: len(got)]), (chunk, maxp, f)
+    with ThreadPoolExecutor(2) as ex:                    # two contexts / streams at once
+        parts = list(ex.map(lambda r: run(8, 21, r[0], r[1]), [(0, 21), (21, 42)]))
+    both = np.concatenate(parts)
+    for f in ref.dtype.names:
+        assert np.array_equal(both[f], ref[f]), f
