@@ -88,6 +88,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--sequence", action="store_true",
                     help="extra diagnostic: also time vo_sequence_run_device on the A frames taken as one sequence (each frame extracted once)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo to rehearse several ranks on one GPU)")
     ap.add_argument("--config4", action="store_true",
                     help="diagnostic: run configs[3] instead (3840x2160 frames, 20000 ORB features; use e.g. --pairs 16 --distinct 4 --chunk 4)")
     args = ap.parse_args()
@@ -103,10 +104,15 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU fallback")
+    if args.backend != "nccl":
+        local_rank %= torch.cuda.device_count()      # rehearsal: several ranks share the visible GPUs
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=args.backend)
 
     from visual_slam_amd import _lib, parallel, synth
 
