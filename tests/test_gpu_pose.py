@@ -246,3 +246,26 @@ def test_batching_is_invisible(K02):
     both = np.concatenate(parts)
     for f in ref.dtype.names:
         assert np.array_equal(both[f], ref[f]), f
+
+
+def test_many_synthetic_pairs_match_oracle(oracle):
+    """A sweep of seeded config-2 pairs (the bench workload) through the batched path vs the oracle, pair by pair:
+    status, keypoint / match / inlier counts exactly, pose within 1e-6 rad.  Catches rare-path divergences
+    (retainBest ties, ragged matcher blocks, second RANSAC rounds) that single fixtures cannot."""
+    from concurrent.futures import ThreadPoolExecutor
+    from visual_slam_amd import _lib, synth
+    seeds = list(range(100, 196))
+    a, b = synth.make_batch(seeds, workers=1)
+    K = synth.K_KITTI02
+    c = _lib.Context(max_w=a.shape[2], max_h=a.shape[1], chunk_pairs=7, max_pairs=len(seeds))
+    try:
+        res = c.pairs_run(a, b, K)
+    finally:
+        c.close()
+    with ThreadPoolExecutor(8) as ex:          # ctypes releases the GIL: the oracle runs on 8 host threads
+        ref = list(ex.map(lambda i: oracle.pair_run(a[i], b[i], K), range(len(seeds))))
+    for i, (rc, T, counts) in enumerate(ref):
+        r = res[i]
+        assert rc == r["status"] == 0, seeds[i]
+        assert [r["n_kp1"], r["n_kp2"], r["n_match"], r["n_inlier"]] == counts.tolist(), seeds[i]
+        assert rot_angle(T[:3, :3], r["T"][:3, :3]) < 1e-6 and dir_angle(T[:3, 3], r["T"][:3, 3]) < 1e-6, seeds[i]
