@@ -73,7 +73,8 @@ def test_blur_and_fma_variants(oracle, kitti02, mode, fma):
 def test_detect_other_sizes_and_params(oracle, kitti02):
     from visual_slam_amd import _lib
     rng = np.random.default_rng(5)
-    for (h, w, nf, nl) in [(200, 320, 500, 8), (376, 1241, 3000, 4), (96, 128, 200, 3), (150, 150, 1000, 8)]:
+    for (h, w, nf, nl) in [(200, 320, 500, 8), (376, 1241, 3000, 4), (96, 128, 200, 3), (150, 150, 1000, 8),
+                           (233, 317, 800, 8), (75, 1241, 300, 2), (376, 71, 100, 2), (301, 997, 2000, 6)]:   # odd sizes, thin frames
         img = kitti02[3][:h, :w].copy() if h <= 376 else None
         if rng.integers(0, 2):
             img = (img.astype(np.int32) + rng.integers(-20, 20, img.shape)).clip(0, 255).astype(np.uint8)
