@@ -67,8 +67,27 @@ def cpu_baseline(imgsA, imgsB, K, budget_s=12.0):
         rc, _, _ = O.pair_run(imgsA[n], imgsB[n], K)
         n += 1
     dt = time.perf_counter() - t0
-    return {"value": n / dt, "unit": "frame-pairs/sec", "cores": 1, "kind": "port",
-            "sample": "first %d pairs of rank 0's batch, scalar C++ oracle (restated cv2 ORB+BFMatcher+findEssentialMat+recoverPose), 1 thread" % n}
+    out = {"value": n / dt, "unit": "frame-pairs/sec", "cores": 1, "kind": "port",
+           "sample": "first %d pairs of rank 0's batch, scalar C++ oracle (restated cv2 ORB+BFMatcher+findEssentialMat+recoverPose), 1 thread" % n}
+    try:      # SURVEY.md 8(d) "live cv2": never installed or fetched; timed beside the port only where a box already has it
+        import cv2
+    except ImportError:
+        out["cv2"] = None
+        return out
+    cv2.setNumThreads(1)
+    orb, bf = cv2.ORB_create(NFEAT), cv2.BFMatcher(cv2.NORM_HAMMING)
+    m, t0 = 0, time.perf_counter()
+    while m < len(imgsA) and (time.perf_counter() - t0 < budget_s or m < 2):
+        k1, f1 = orb.detectAndCompute(imgsA[m], None)
+        k2, f2 = orb.detectAndCompute(imgsB[m], None)
+        good = [a for a, b in bf.knnMatch(f1, f2, k=2) if a.distance < 0.45 * b.distance]
+        q1 = np.float32([k1[g.queryIdx].pt for g in good]); q2 = np.float32([k2[g.trainIdx].pt for g in good])
+        E, mask = cv2.findEssentialMat(q1, q2, K, cv2.RANSAC, 0.999, 1.0, None)
+        cv2.recoverPose(E, q1, q2, K, mask)
+        m += 1
+    out["cv2"] = {"value": m / (time.perf_counter() - t0), "unit": "frame-pairs/sec", "cores": 1, "version": cv2.__version__,
+                  "sample": "first %d pairs, cv2 ORB + BFMatcher + findEssentialMat + recoverPose, setNumThreads(1)" % m}
+    return out
 
 
 def main():

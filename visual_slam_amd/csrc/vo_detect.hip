@@ -1041,12 +1041,18 @@ __device__ __forceinline__ float comp4(const float4& v, int j) { return j == 0 ?
 __device__ __forceinline__ int comp4(const int4& v, int j) { return j == 0 ? v.x : j == 1 ? v.y : j == 2 ? v.z : v.w; }
 
 #define BL_SP 80                      // LDS source tile pitch (bytes): 72 used
+#define BL_RPL 4                      // output rows per lane in the column pass (VO_BLUR_TH = 16 * BL_RPL)
 #define BL_ROWS (VO_BLUR_TH + 6)
+static_assert(VO_BLUR_TH == 16 * BL_RPL && VO_BLUR_TW == 64 && BL_ROWS % 14 == 0, "k_blur lane mapping");
 
 // Tile = 64 x VO_BLUR_TH outputs.  Source window = (TH+6) rows x 72 bytes from the dword boundary
 // x0-4.  Row pass: one lane makes 4 adjacent outputs from 3 LDS dwords (10 bytes -> float by
-// v_cvt_f32_ubyteN) and stores a float4; column pass: one lane makes 4 adjacent outputs from 7
-// float4 rows and stores one dword.  The multiply/add order is sepFilter2D's.
+// v_cvt_f32_ubyteN) and stores a float4; column pass: one lane makes 4 adjacent outputs on each of
+// BL_RPL consecutive rows from BL_RPL+6 float4 rows held in registers (every row-pass value is read
+// from LDS 2.5 times instead of 7) and stores BL_RPL dwords.  The multiply/add order is
+// sepFilter2D's.
+// MODE (blur_mode) and FMA (vo_orb_params.fma) are template parameters: as run-time flags they left a branch per output pixel.
+template <int MODE, bool FMA>
 __global__ __launch_bounds__(256) void k_blur(const Geom* __restrict__ g, FrameSrc src, const uint8_t* __restrict__ pyr,
                                               uint8_t* __restrict__ blur, const TileDesc* __restrict__ btiles, BlurK bk, int nframes) {
     __shared__ __attribute__((aligned(16))) uint8_t sp[BL_ROWS * BL_SP];
@@ -1059,22 +1065,21 @@ __global__ __launch_bounds__(256) void k_blur(const Geom* __restrict__ g, FrameS
     int pitch;
     const uint8_t* img = level_ptr(g, src, pyr, f, td.level, pitch);
     const int x0 = td.tx * VO_BLUR_TW, y0 = td.ty * VO_BLUR_TH;
+    const int nrows = min(BL_ROWS, L.h - y0 + 6);      // source rows the tile's outputs (y < L.h) reach
     if (x0 - 4 >= 0 && x0 + 68 <= L.w && y0 - 3 >= 0 && y0 - 3 + BL_ROWS <= L.h) {
-        // interior tile (workgroup-uniform): no reflection, one address and two strides per lane (252 lanes x 14 rows x 3)
+        // interior tile (workgroup-uniform): no reflection, one address and one stride per lane (252 lanes x 14 rows x 5)
         if (tid < 252) {
             const int r0 = tid / 18, k = tid - r0 * 18;
             const uint8_t* p = img + (long)(y0 - 3 + r0) * pitch + (x0 - 4 + 4 * k);
             uint32_t* q = reinterpret_cast<uint32_t*>(&sp[r0 * BL_SP + 4 * k]);
-            uint32_t v0, v1, v2 = 0;
-            __builtin_memcpy(&v0, p, 4);
-            __builtin_memcpy(&v1, p + 14L * pitch, 4);
-            if (r0 + 28 < BL_ROWS) __builtin_memcpy(&v2, p + 28L * pitch, 4);
-            q[0] = v0;
-            q[14 * BL_SP / 4] = v1;
-            if (r0 + 28 < BL_ROWS) q[28 * BL_SP / 4] = v2;
+            uint32_t v[BL_ROWS / 14];
+#pragma unroll
+            for (int j = 0; j < BL_ROWS / 14; j++) __builtin_memcpy(&v[j], p + 14L * j * pitch, 4);
+#pragma unroll
+            for (int j = 0; j < BL_ROWS / 14; j++) q[14 * j * BL_SP / 4] = v[j];
         }
     } else {
-        for (int i = tid; i < BL_ROWS * 18; i += 256) {
+        for (int i = tid; i < nrows * 18; i += 256) {
             const int r = i / 18, k = i - r * 18;
             const int y = reflect101c(y0 - 3 + r, L.h), x = x0 - 4 + 4 * k;
             const uint8_t* rp = img + (long)y * pitch;
@@ -1090,10 +1095,17 @@ __global__ __launch_bounds__(256) void k_blur(const Geom* __restrict__ g, FrameS
         }
     }
     __syncthreads();
-    const bool use_fma = g->fma != 0;
-    const int mode = g->blur_mode;
+    constexpr bool use_fma = FMA;
+    constexpr int mode = MODE;
+    // the weights live in VGPRs: a VOP2 multiply/fma with an SGPR operand issues at half rate on gfx950 (tools/ubench2.hip)
+    float kw[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        kw[i] = bk.k[i];
+        asm volatile("" : "+v"(kw[i]));
+    }
     int* rowi = reinterpret_cast<int*>(rowf);
-    for (int i = tid; i < BL_ROWS * 16; i += 256) {
+    for (int i = tid; i < nrows * 16; i += 256) {
         const int r = i >> 4, c4 = (i & 15) * 4;
         const uint32_t* q = reinterpret_cast<const uint32_t*>(&sp[r * BL_SP + c4]);
         const uint32_t d0 = q[0], d1 = q[1], d2 = q[2];
@@ -1116,21 +1128,21 @@ __global__ __launch_bounds__(256) void k_blur(const Geom* __restrict__ g, FrameS
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 // RowFilter<uchar,float>: s = k[0]*p[-3]; s += k[i]*p[i-3] left to right
-                float acc = bk.k[3] * fb[j];
+                float acc = kw[3] * fb[j];
                 if (use_fma) {
-                    acc = __fmaf_rn(bk.k[2], fb[j + 1], acc);
-                    acc = __fmaf_rn(bk.k[1], fb[j + 2], acc);
-                    acc = __fmaf_rn(bk.k[0], fb[j + 3], acc);
-                    acc = __fmaf_rn(bk.k[1], fb[j + 4], acc);
-                    acc = __fmaf_rn(bk.k[2], fb[j + 5], acc);
-                    acc = __fmaf_rn(bk.k[3], fb[j + 6], acc);
+                    acc = __fmaf_rn(kw[2], fb[j + 1], acc);
+                    acc = __fmaf_rn(kw[1], fb[j + 2], acc);
+                    acc = __fmaf_rn(kw[0], fb[j + 3], acc);
+                    acc = __fmaf_rn(kw[1], fb[j + 4], acc);
+                    acc = __fmaf_rn(kw[2], fb[j + 5], acc);
+                    acc = __fmaf_rn(kw[3], fb[j + 6], acc);
                 } else {
-                    acc = acc + bk.k[2] * fb[j + 1];
-                    acc = acc + bk.k[1] * fb[j + 2];
-                    acc = acc + bk.k[0] * fb[j + 3];
-                    acc = acc + bk.k[1] * fb[j + 4];
-                    acc = acc + bk.k[2] * fb[j + 5];
-                    acc = acc + bk.k[3] * fb[j + 6];
+                    acc = acc + kw[2] * fb[j + 1];
+                    acc = acc + kw[1] * fb[j + 2];
+                    acc = acc + kw[0] * fb[j + 3];
+                    acc = acc + kw[1] * fb[j + 4];
+                    acc = acc + kw[2] * fb[j + 5];
+                    acc = acc + kw[3] * fb[j + 6];
                 }
                 op[j] = acc;
             }
@@ -1138,49 +1150,62 @@ __global__ __launch_bounds__(256) void k_blur(const Geom* __restrict__ g, FrameS
         }
     }
     __syncthreads();
-    for (int i = tid; i < VO_BLUR_TH * 16; i += 256) {
-        const int r = i >> 4, c4 = (i & 15) * 4;
-        const int y = y0 + r;
-        if (y >= L.h || x0 + c4 >= L.w) continue;
-        uint32_t packed = 0;
+    {
+        const int c4 = (tid & 15) * 4, r0 = (tid >> 4) * BL_RPL;
+        if (y0 + r0 >= L.h || x0 + c4 >= L.w) return;
+        uint32_t packed[BL_RPL];
         if (mode == 1) {
-            int4 q[7];
+            int4 q[BL_RPL + 6];
 #pragma unroll
-            for (int k = 0; k < 7; k++) q[k] = *reinterpret_cast<const int4*>(&rowi[(r + k) * VO_BLUR_TW + c4]);
+            for (int k = 0; k < BL_RPL + 6; k++)
+                if (r0 + k < nrows) q[k] = *reinterpret_cast<const int4*>(&rowi[(r0 + k) * VO_BLUR_TW + c4]);
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const int s = 18 * (comp4(q[0], j) + comp4(q[6], j)) + 34 * (comp4(q[1], j) + comp4(q[5], j)) +
-                              49 * (comp4(q[2], j) + comp4(q[4], j)) + 55 * comp4(q[3], j);
-                // s >= 0 here, so an unsigned shift + umin is the saturate_cast.  (Written this way on purpose:
-                // hipcc 7.2 folds `clamp(x >> 16, 0, 255)` pairs into v_ashr_pk_u8_i32 and then ORs byte 2
-                // over its upper half, which the instruction does not leave zero on gfx950 -- wrong pixels.)
-                packed |= min((uint32_t)(s + 32768) >> 16, 255u) << (8 * j);
+            for (int o = 0; o < BL_RPL; o++) {
+                packed[o] = 0;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int s = 18 * (comp4(q[o], j) + comp4(q[o + 6], j)) + 34 * (comp4(q[o + 1], j) + comp4(q[o + 5], j)) +
+                                  49 * (comp4(q[o + 2], j) + comp4(q[o + 4], j)) + 55 * comp4(q[o + 3], j);
+                    // s >= 0 here, so an unsigned shift + umin is the saturate_cast.  (Written this way on purpose:
+                    // hipcc 7.2 folds `clamp(x >> 16, 0, 255)` pairs into v_ashr_pk_u8_i32 and then ORs byte 2
+                    // over its upper half, which the instruction does not leave zero on gfx950 -- wrong pixels.)
+                    packed[o] |= min((uint32_t)(s + 32768) >> 16, 255u) << (8 * j);
+                }
             }
         } else {
-            float4 q[7];
+            float4 q[BL_RPL + 6];
 #pragma unroll
-            for (int k = 0; k < 7; k++) q[k] = *reinterpret_cast<const float4*>(&rowf[(r + k) * VO_BLUR_TW + c4]);
+            for (int k = 0; k < BL_RPL + 6; k++)
+                if (r0 + k < nrows) q[k] = *reinterpret_cast<const float4*>(&rowf[(r0 + k) * VO_BLUR_TW + c4]);
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                // SymmColumnFilter: s = k0*row[0] + delta; s += k[i]*(row[i] + row[-i])
-                float acc = bk.k[0] * comp4(q[3], j) + 0.f;
-                const float t1 = comp4(q[4], j) + comp4(q[2], j);
-                const float t2 = comp4(q[5], j) + comp4(q[1], j);
-                const float t3 = comp4(q[6], j) + comp4(q[0], j);
-                if (use_fma) {
-                    acc = __fmaf_rn(bk.k[1], t1, acc);
-                    acc = __fmaf_rn(bk.k[2], t2, acc);
-                    acc = __fmaf_rn(bk.k[3], t3, acc);
-                } else {
-                    acc = acc + bk.k[1] * t1;
-                    acc = acc + bk.k[2] * t2;
-                    acc = acc + bk.k[3] * t3;
+            for (int o = 0; o < BL_RPL; o++) {
+                packed[o] = 0;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    // SymmColumnFilter: s = k0*row[0] + delta; s += k[i]*(row[i] + row[-i])
+                    float acc = kw[0] * comp4(q[o + 3], j) + 0.f;
+                    const float t1 = comp4(q[o + 4], j) + comp4(q[o + 2], j);
+                    const float t2 = comp4(q[o + 5], j) + comp4(q[o + 1], j);
+                    const float t3 = comp4(q[o + 6], j) + comp4(q[o], j);
+                    if (use_fma) {
+                        acc = __fmaf_rn(kw[1], t1, acc);
+                        acc = __fmaf_rn(kw[2], t2, acc);
+                        acc = __fmaf_rn(kw[3], t3, acc);
+                    } else {
+                        acc = acc + kw[1] * t1;
+                        acc = acc + kw[2] * t2;
+                        acc = acc + kw[3] * t3;
+                    }
+                    // saturate_cast<uchar>(cvRound(acc)): 0 <= acc <= 255 * (sum of weights) < 255.5, so after the
+                    // round-half-even the value is an integer in [0, 255] and the byte conversion is exact
+                    packed[o] = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_rintf(acc), j, packed[o]);
                 }
-                packed |= (uint32_t)min(max(__float2int_rn(acc), 0), 255) << (8 * j);
             }
         }
-        uint8_t* dp = blur + (long)f * g->blur_frame + L.blur_ofs + (long)y * L.bpitch + x0 + c4;
-        *reinterpret_cast<uint32_t*>(dp) = packed;
+        uint8_t* dp = blur + (long)f * g->blur_frame + L.blur_ofs + (long)(y0 + r0) * L.bpitch + x0 + c4;
+#pragma unroll
+        for (int o = 0; o < BL_RPL; o++)
+            if (y0 + r0 + o < L.h) *reinterpret_cast<uint32_t*>(dp + (long)o * L.bpitch) = packed[o];
     }
 }
 
@@ -1331,12 +1356,13 @@ int vo_launch_detect(vo_ctx* c, const FrameSrc& src, int F, hipStream_t st) {
     // leave most of the chip idle), and joins before the descriptors.
     BlurK bk;
     gaussian_kernel7_sigma2(bk);
+    auto blur_fn = g.blur_mode == 1 ? k_blur<1, false> : (g.fma ? k_blur<0, true> : k_blur<0, false>);
     static const bool serial = getenv("VO_SERIAL") != nullptr;   // profiling aid: one kernel at a time, so trace durations are per kernel
     const bool fork_blur = !serial && !c->timing && c->debug_stop == 0 && c->aux_stream != nullptr;
     if (fork_blur) {
         HIP_TRY(c, hipEventRecord(c->ev_fork, st));
         HIP_TRY(c, hipStreamWaitEvent(c->aux_stream, c->ev_fork, 0));
-        hipLaunchKernelGGL(k_blur, dim3(pad8(g.nbtiles * F)), dim3(256), 0, c->aux_stream, dg, src, pyr, blur, (const TileDesc*)c->d_btiles.p, bk, F);
+        hipLaunchKernelGGL(blur_fn, dim3(pad8(g.nbtiles * F)), dim3(256), 0, c->aux_stream, dg, src, pyr, blur, (const TileDesc*)c->d_btiles.p, bk, F);
         HIP_TRY(c, hipEventRecord(c->ev_join, c->aux_stream));
     }
     if (g.ntiles > 0) {
@@ -1359,7 +1385,7 @@ int vo_launch_detect(vo_ctx* c, const FrameSrc& src, int F, hipStream_t st) {
     KT(c, st, VO_K_ORIENT, hipLaunchKernelGGL(k_orient, dim3(pad8(ORIENT_BX * g.nlevels * F)), dim3(256), 0, st, dg, src, pyr, cnt_sel2, key, payload, (vo_keypoint*)c->d_kp.p,
                        (uint32_t*)c->d_kplvl.p, (int*)c->d_nkp.p, (int*)c->d_frame_status.p, F));
     if (fork_blur) HIP_TRY(c, hipStreamWaitEvent(st, c->ev_join, 0));
-    else KT(c, st, VO_K_BLUR, hipLaunchKernelGGL(k_blur, dim3(pad8(g.nbtiles * F)), dim3(256), 0, st, dg, src, pyr, blur, (const TileDesc*)c->d_btiles.p, bk, F));
+    else KT(c, st, VO_K_BLUR, hipLaunchKernelGGL(blur_fn, dim3(pad8(g.nbtiles * F)), dim3(256), 0, st, dg, src, pyr, blur, (const TileDesc*)c->d_btiles.p, bk, F));
     const int rb_nbx = (g.kp_cap + RB_KPB - 1) / RB_KPB;
     KT(c, st, VO_K_RBRIEF, hipLaunchKernelGGL(k_rbrief, dim3(pad8(rb_nbx * F)), dim3(256), 0, st, dg, blur, (const signed char*)c->d_pat.p, (const int*)c->d_nkp.p,
                        (const vo_keypoint*)c->d_kp.p, (const uint32_t*)c->d_kplvl.p, (uint8_t*)c->d_desc.p, rb_nbx, F));

@@ -13,7 +13,7 @@
 #define VO_TILE_H 30
 #define VO_TILE_CAP 512     // a 60x30 tile holds at most 30*15 = 450 strict 3x3 maxima
 #define VO_BLUR_TW 64
-#define VO_BLUR_TH 32
+#define VO_BLUR_TH 64
 
 struct LevelGeom {
     int w, h, pitch;        // level size; row pitch of the level inside the pyramid slab
