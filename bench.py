@@ -101,10 +101,12 @@ def main():
     ap.add_argument("--workers", type=int, default=0, help="host processes for input generation (0 = auto; use 1 under rocprofv3)")
     ap.add_argument("--streams", type=int, default=2,
                     help="contexts (one HIP stream and workspace each) driven by one host thread each; the batch is split between them")
+    ap.add_argument("--join-steps", action="store_true", help="diagnostic: all contexts finish a step before any starts the next one")
     ap.add_argument("--ba", action="store_true",
                     help="extra diagnostic: time the BA residual/Jacobian pass of configs[4] (1000 poses x 200k points x 5 obs, points "
                          "sharded over ranks, pose blocks all-reduced over RCCL)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--lib", default=None, help="diagnostic: load this build of libvo_mi355.so instead of the in-tree one (A/B runs of kernel variants)")
     ap.add_argument("--sequence", action="store_true",
                     help="extra diagnostic: also time vo_sequence_run_device on the A frames taken as one sequence (each frame extracted once)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo to rehearse several ranks on one GPU)")
@@ -134,6 +136,8 @@ def main():
             dist.init_process_group(backend=args.backend)
 
     from visual_slam_amd import _lib, parallel, synth
+    if args.lib:
+        _lib.SO_PATH = os.path.abspath(args.lib)
 
     B = args.pairs
     workers = args.workers if args.workers > 0 else max(1, min(12, (os.cpu_count() or 1) // max(world, 1)))
@@ -160,24 +164,37 @@ def main():
         lo, hi = bounds[i]
         return ctxs[i].pairs_run_device(dA.data_ptr() + lo * fsz, dB.data_ptr() + lo * fsz, hi - lo, W_IMG, H_IMG, W_IMG, K)
 
-    def step():
-        # this rank's shard of the job (split over S contexts/streams; ctypes calls release the GIL), then (N > 1)
-        # the only collective of the path: an RCCL all_gather of the 152-byte per-pair result records
-        local = np.concatenate(list(pool.map(run_part, range(S)))) if pool else run_part(0)
-        return parallel.gather_pair_results(local, world * B) if world > 1 else local
+    def ctx_passes(i, nsteps):
+        """Context i makes `nsteps` passes over its share as back-to-back calls: its host thread does not wait for the other
+        contexts between passes, so one context's latency-bound pose stage (end of a call) overlaps the detect/match chunks
+        of the others instead of all contexts reaching it together (measured +7 % over joining after every step; shifting the
+        contexts half a pass out of phase on purpose measured no better).  Returns the records pass by pass."""
+        lo, hi = bounds[i]
+        return [ctxs[i].pairs_run_device(dA.data_ptr() + lo * fsz, dB.data_ptr() + lo * fsz, hi - lo, W_IMG, H_IMG, W_IMG, K) for _ in range(nsteps)]
+
+    def run_steps(nsteps):
+        # this rank's shard of the job, split over S contexts/streams (ctypes calls release the GIL); then (N > 1) the only
+        # collective of the path, once per step: an RCCL all_gather of the 152-byte per-pair result records
+        parts = list(pool.map(lambda i: ctx_passes(i, nsteps), range(S))) if pool else [ctx_passes(0, nsteps)]
+        last = None
+        for k in range(nsteps):
+            local = np.concatenate([parts[i][k] for i in range(S)])
+            last = parallel.gather_pair_results(local, world * B) if world > 1 else local
+        return last
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    res = None
-    for _ in range(args.warmup):
-        res = step()
+    res = run_steps(args.warmup)
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        res = step()
+    if args.join_steps:
+        for _ in range(args.steps):
+            res = run_steps(1)
+    else:
+        res = run_steps(args.steps)
     barrier()
     dt = time.perf_counter() - t0
     dt = parallel.max_over_ranks(dt)
@@ -280,7 +297,7 @@ def main():
             "dtype": "u8/int32 detect+match, f64 pose", "data": "synthetic",
             "config": {"workload": ("configs[2]: batch of synthetic 1241x376 pairs (configs[1] generator, seeds 0..), 3000 ORB features, 8 levels" if not args.config4 else
                                     "configs[3] (diagnostic): synthetic 3840x2160 pairs, 20000 ORB features, 8 levels"),
-                       "pairs_per_gpu": B, "distinct_pairs_per_gpu": nd, "global_pairs": world * B, "chunk_pairs": min(args.chunk, B), "streams_per_gpu": S, "parallelism": "pairs sharded over ranks, no collective",
+                       "pairs_per_gpu": B, "distinct_pairs_per_gpu": nd, "global_pairs": world * B, "chunk_pairs": min(args.chunk, B), "streams_per_gpu": S, "contexts_join_every_step": bool(args.join_steps), "parallelism": "pairs sharded over ranks, no collective",
                        "pairs_ok": ok, "pairs_total": int(len(res))},
             "roofline": roofline, "cpu_baseline": cpu, "sequence_mode": seq, "ba_pass": ba_out, "kernels": kernels,
         }

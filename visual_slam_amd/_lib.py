@@ -49,6 +49,13 @@ def load():
         raise RuntimeError(
             "libvo_mi355.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'`; "
             "there is no CPU fallback." % SO_PATH)
+    # PyTorch-ROCm wheels bundle their own HIP runtime (torch/lib/libamdhip64.so).  The dynamic linker shares one copy
+    # by SONAME only if torch's is loaded first; loading this library (linked against /opt/rocm) first and torch
+    # afterwards leaves torch with "No HIP GPUs are available".  So where torch exists, import it before the library.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(SO_PATH)
     vp, i, d = C.c_void_p, C.c_int, C.c_double
     lib.vo_ctx_create.argtypes = [i, i, i, i, i, vp, C.POINTER(vp)]
