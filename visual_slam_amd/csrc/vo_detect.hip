@@ -305,6 +305,8 @@ __global__ __launch_bounds__(256) void k_fast_tiles(const Geom* __restrict__ g, 
     __shared__ int bmpre[64];            // exclusive prefix of the popcounts of bm
     __shared__ uint16_t queue[FQ_CAP];   // brighter-arc candidates from the front, darker-arc candidates from the back
     __shared__ int qcnt;                 // brighter count | darker count << 16
+    __shared__ uint16_t corner[64 * 32]; // positions with a score > 0
+    __shared__ int ccnt;
     const VBlock vb = xcd_block(g->ntiles, 1, nframes);
     if (!vb.valid) return;
     const int t = vb.x, f = vb.f, tid = threadIdx.x;
@@ -318,7 +320,7 @@ __global__ __launch_bounds__(256) void k_fast_tiles(const Geom* __restrict__ g, 
     // 38 rows x 72 bytes from the dword boundary xa = x0-4-PXO (a multiple of 4), as 18 dwords per row;
     // 252 lanes cover 14 rows per pass
     const int xa = x0 - 4 - PXO;
-    if (tid == 0) qcnt = 0;
+    if (tid == 0) { qcnt = 0; ccnt = 0; }
     if (tid >= 192) bm[tid - 192] = 0;
     if (tid < 252) {
         const int r0 = tid / 18, k = tid - r0 * 18;
@@ -408,34 +410,49 @@ __global__ __launch_bounds__(256) void k_fast_tiles(const Geom* __restrict__ g, 
         if (pd3) queue[od - nd0 - nd1 - nd2 - lanes_below(md3)] = (uint16_t)(pos + 3);
     }
     __syncthreads();
-    // Stage 2: arc extremes + cornerScore of the queued positions.  A position in both queues (an edge
-    // through the centre) takes the larger of its two scores: the darker pass runs after a barrier.
+    // Stage 2: arc extremes + cornerScore of the queued positions, both queues in one pass: the darker queue starts at
+    // the next multiple of 64 after the brighter one, so every wavefront is polarity-uniform.  A position cannot have a
+    // brighter AND a darker arc of 9 (two arcs of 9 on a circle of 16 overlap), so at most one of its two visits finds
+    // a score > 0 and stores it (the score tile was zeroed in stage 1).  Corners are pushed to a third list.
     const int nb = qcnt & 0xFFFF, nd = qcnt >> 16;
-    for (int q = tid; q < nb; q += 256) {
-        const int i = queue[q];
-        const int r = i >> 6, c = i & 63;
-        const uint8_t* p = &px[(r + 3) * PXP + c + 3 + PXO];
-        const int best = fast_arc_extreme<true>(p) - (int)p[0];
-        sc[i] = (uint8_t)(best > thr ? best - 1 : 0);
+    const int nb64 = (nb + 63) & ~63;
+    for (int q = tid; q < nb64 + nd; q += 256) {
+        int i = -1, val = 0;
+        if (q < nb64) {
+            if (q < nb) {
+                i = queue[q];
+                const uint8_t* p = &px[((i >> 6) + 3) * PXP + (i & 63) + 3 + PXO];
+                const int best = fast_arc_extreme<true>(p) - (int)p[0];
+                val = best > thr ? best - 1 : 0;
+            }
+        } else {
+            i = queue[FQ_CAP - 1 - (q - nb64)];
+            const uint8_t* p = &px[((i >> 6) + 3) * PXP + (i & 63) + 3 + PXO];
+            const int best = (int)p[0] - fast_arc_extreme<false>(p);
+            val = best > thr ? best - 1 : 0;
+        }
+        const unsigned long long m = __ballot(val > 0);
+        if (m) {
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&ccnt, (int)__popcll(m));
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (val > 0) {
+                sc[i] = (uint8_t)val;
+                corner[base + lanes_below(m)] = (uint16_t)i;
+            }
+        }
     }
     __syncthreads();
-    for (int q = tid; q < nd; q += 256) {
-        const int i = queue[FQ_CAP - 1 - q];
-        const int r = i >> 6, c = i & 63;
-        const uint8_t* p = &px[(r + 3) * PXP + c + 3 + PXO];
-        const int best = (int)p[0] - fast_arc_extreme<false>(p);
-        sc[i] = (uint8_t)max((int)sc[i], best > thr ? best - 1 : 0);
-    }
-    __syncthreads();
-    // Stage 3: strict 3x3 non-max suppression + border filter, only at the queued positions; a survivor sets
-    // its bit in a 60 x 30 bitmap (row r = dwords 2r, 2r+1), whose bit order is raster order
-    for (int q = tid; q < nb + nd; q += 256) {
-        const int i = q < nb ? queue[q] : queue[FQ_CAP - 1 - (q - nb)];
+    // Stage 3: strict 3x3 non-max suppression + border filter at the corners; a survivor sets its bit in a 60 x 30
+    // bitmap (row r = dwords 2r, 2r+1), whose bit order is raster order
+    const int nc = ccnt;
+    for (int q = tid; q < nc; q += 256) {
+        const int i = corner[q];
         const int r = i >> 6, c = i & 63;                      // score position; output (r-1, c-1)
         const uint8_t* s0 = &sc[i];
         const int s = s0[0];
         const int xi = x0 - 1 + c, yi = y0 - 1 + r;
-        if (s != 0 && r >= 1 && r <= VO_TILE_H && c >= 1 && c <= VO_TILE_W && xi < Lw - VO_EDGE && yi < Lh - VO_EDGE &&
+        if (r >= 1 && r <= VO_TILE_H && c >= 1 && c <= VO_TILE_W && xi < Lw - VO_EDGE && yi < Lh - VO_EDGE &&
             s > s0[-1] && s > s0[1] && s > s0[-SCP - 1] && s > s0[-SCP] && s > s0[-SCP + 1] && s > s0[SCP - 1] && s > s0[SCP] && s > s0[SCP + 1])
             atomicOr(&bm[(r - 1) * 2 + ((c - 1) >> 5)], 1u << ((c - 1) & 31));
     }
@@ -453,8 +470,8 @@ __global__ __launch_bounds__(256) void k_fast_tiles(const Geom* __restrict__ g, 
     }
     __syncthreads();
     uint32_t* tl = tile_list + ((long)f * g->ntiles + t) * VO_TILE_CAP;
-    for (int q = tid; q < nb + nd; q += 256) {
-        const int i = q < nb ? queue[q] : queue[FQ_CAP - 1 - (q - nb)];
+    for (int q = tid; q < nc; q += 256) {
+        const int i = corner[q];
         const int r = (i >> 6) - 1, c = (i & 63) - 1;          // output position
         if (r < 0 || r >= VO_TILE_H || c < 0 || c >= VO_TILE_W) continue;
         const int d = r * 2 + (c >> 5), bit = c & 31;
