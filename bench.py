@@ -37,12 +37,12 @@ HBM_PEAK_GBS = 8000.0
 # matcher: one Hamming distance = a 256-long i8 dot product on the matrix cores = 512 ops;
 # dense i8 MFMA peak = 2 x bf16 = 256 CU x 4 SIMD x 2048 ops/clk x 2.4 GHz (MI355X_MICROARCH.md, Matrix cores)
 MFMA_I8_PEAK_TOPS = 256 * 4 * 2048 * 2.4e9 / 1e12
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r1_d_pmc_hbm_traffic.json")
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r1_f_pmc_hbm_traffic.json")
 
 
 def measured_traffic(kernel, frames_per_launch):
     """HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE + WRITE_SIZE, KB, separate
-    runs of this script; profiles/r1_d_pmc_hbm_traffic.json), scaled to this run's frames per launch.
+    runs of this script; profiles/r1_f_pmc_hbm_traffic.json), scaled to this run's frames per launch.
     None when the file or the kernel is missing: bench.py itself never runs the profiler."""
     try:
         with open(TRAFFIC_FILE) as f:
