@@ -168,6 +168,10 @@ int vo_build_geometry(vo_ctx* c, int w, int h) {
 // One lane makes 4 adjacent pixels: one 16-byte coefficient load, one 8-byte load from each of
 // the two source rows (the 4 outputs read at most 7 consecutive source bytes for scale <= 2),
 // one dword store.
+typedef unsigned short pyr_u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pyr_dot2(uint32_t a, uint32_t b, uint32_t c) {
+    return __builtin_amdgcn_udot2(__builtin_bit_cast(pyr_u16x2, a), __builtin_bit_cast(pyr_u16x2, b), c, false);
+}
 #define PYR_ROWS 4   // output rows per lane: their source loads are issued together (the kernel is latency bound)
 __global__ __launch_bounds__(256) void k_pyramid(const Geom* __restrict__ g, FrameSrc src, uint8_t* __restrict__ pyr,
                                                  const ResizeCoef* __restrict__ rt, int l) {
@@ -196,27 +200,30 @@ __global__ __launch_bounds__(256) void k_pyramid(const Geom* __restrict__ g, Fra
             __builtin_memcpy(&a[r], sp + (long)oy * spitch + o0, 8);
             __builtin_memcpy(&b[r], sp + (long)min(oy + 1, sh - 1) * spitch + o0, 8);
         }
-        // v_perm_b32 selectors picking source bytes (rel, rel+1) of the 8 loaded ones -- the same for all rows of the lane
-        uint32_t sel[4], c1v[4];
+        // v_perm_b32 selectors placing source bytes (rel, rel+1) of the 8 loaded ones as a u16 pair, and the weight pair
+        // c0 | c1 << 16 -- the same for all rows of the lane; H = c0*p[i] + c1*p[i+1] is then one v_dot2_u32_u16, and
+        // so is c0y*H0 + c1y*H1 + 32768 on the pair H0 | H1 << 16 (H < 2^16); the pixel is byte 2 of that sum (< 2^24)
+        uint32_t sel[4], cxp[4];
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            const uint32_t rel = (cx[i] & 0xFFFF) - (uint32_t)o0;
-            sel[i] = 0x0C0C0100u + rel * 0x0101u;
-            c1v[i] = cx[i] >> 16;
+            const uint32_t rel = (cx[min(i, nvalid - 1)] & 0xFFFF) - (uint32_t)o0;
+            sel[i] = 0x0C010C00u + rel * 0x00010001u;
+            cxp[i] = 256u + (cx[min(i, nvalid - 1)] >> 16) * 65535u;
         }
 #pragma unroll
         for (int r = 0; r < PYR_ROWS; r++) {
-            const uint32_t c1y = cyv[r] >> 16, c0y = 256 - c1y;
-            uint32_t packed = 0;
+            const uint32_t cyp = 256u + (cyv[r] >> 16) * 65535u;
+            uint32_t v[4];
 #pragma unroll
             for (int i = 0; i < 4; i++) {
-                if (i < nvalid) {
-                    const uint32_t c1 = c1v[i], c0 = 256 - c1;
-                    const uint32_t pa = __builtin_amdgcn_perm(a[r].y, a[r].x, sel[i]), pb = __builtin_amdgcn_perm(b[r].y, b[r].x, sel[i]);
-                    const uint32_t h0 = c0 * (pa & 0xFF) + c1 * (pa >> 8), h1 = c0 * (pb & 0xFF) + c1 * (pb >> 8);
-                    packed |= ((c0y * h0 + c1y * h1 + 32768u) >> 16) << (8 * i);
-                }
+                const uint32_t h0 = pyr_dot2(__builtin_amdgcn_perm(a[r].y, a[r].x, sel[i]), cxp[i], 0u);
+                const uint32_t h1 = pyr_dot2(__builtin_amdgcn_perm(b[r].y, b[r].x, sel[i]), cxp[i], 0u);
+                v[i] = pyr_dot2(h0 | (h1 << 16), cyp, 32768u);
             }
+            // bytes 2 of v0..v3; columns past the level's width (the last group of a row) are written as 0, as before
+            const uint32_t p01 = __builtin_amdgcn_perm(v[1], v[0], 0x0C0C0602u), p23 = __builtin_amdgcn_perm(v[3], v[2], 0x0C0C0602u);
+            uint32_t packed = p01 | (p23 << 16);
+            if (nvalid < 4) packed &= 0xFFFFFFFFu >> (8 * (4 - nvalid));
             if (y0 + r < L.h) *reinterpret_cast<uint32_t*>(dp + (long)r * L.pitch) = packed;
         }
     } else {
