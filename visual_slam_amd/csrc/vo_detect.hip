@@ -188,7 +188,8 @@ __global__ __launch_bounds__(256) void k_pyramid(const Geom* __restrict__ g, Fra
     const int nvalid = min(4, L.w - x4);
     const int o0 = (int)(cx[0] & 0xFFFF);
     const int olast = (int)(cx[nvalid - 1] & 0xFFFF);
-    uint8_t* dp = pyr + (long)f * g->pyr_frame + L.pyr_ofs + (long)y0 * L.pitch + x4;
+    uint8_t* const lbase = pyr + (long)f * g->pyr_frame + L.pyr_ofs;             // uniform
+    const uint32_t dofs = (uint32_t)y0 * (uint32_t)L.pitch + (uint32_t)x4;
     uint32_t cyv[PYR_ROWS];
 #pragma unroll
     for (int r = 0; r < PYR_ROWS; r++) cyv[r] = rt[L.ytab + min(y0 + r, L.h - 1)];
@@ -196,9 +197,10 @@ __global__ __launch_bounds__(256) void k_pyramid(const Geom* __restrict__ g, Fra
         uint2 a[PYR_ROWS], b[PYR_ROWS];
 #pragma unroll
         for (int r = 0; r < PYR_ROWS; r++) {
-            const int oy = (int)(cyv[r] & 0xFFFF);
-            __builtin_memcpy(&a[r], sp + (long)oy * spitch + o0, 8);
-            __builtin_memcpy(&b[r], sp + (long)min(oy + 1, sh - 1) * spitch + o0, 8);
+            // 32-bit lane offsets from the level's (uniform) base: no 64-bit multiply-adds per load
+            const uint32_t oy = cyv[r] & 0xFFFF;
+            __builtin_memcpy(&a[r], sp + (oy * (uint32_t)spitch + (uint32_t)o0), 8);
+            __builtin_memcpy(&b[r], sp + (min(oy + 1u, (uint32_t)sh - 1u) * (uint32_t)spitch + (uint32_t)o0), 8);
         }
         // v_perm_b32 selectors placing source bytes (rel, rel+1) of the 8 loaded ones as a u16 pair, and the weight pair
         // c0 | c1 << 16 -- the same for all rows of the lane; H = c0*p[i] + c1*p[i+1] is then one v_dot2_u32_u16, and
@@ -224,7 +226,7 @@ __global__ __launch_bounds__(256) void k_pyramid(const Geom* __restrict__ g, Fra
             const uint32_t p01 = __builtin_amdgcn_perm(v[1], v[0], 0x0C0C0602u), p23 = __builtin_amdgcn_perm(v[3], v[2], 0x0C0C0602u);
             uint32_t packed = p01 | (p23 << 16);
             if (nvalid < 4) packed &= 0xFFFFFFFFu >> (8 * (4 - nvalid));
-            if (y0 + r < L.h) *reinterpret_cast<uint32_t*>(dp + (long)r * L.pitch) = packed;
+            if (y0 + r < L.h) *reinterpret_cast<uint32_t*>(lbase + (dofs + (uint32_t)r * (uint32_t)L.pitch)) = packed;
         }
     } else {
 #pragma unroll
@@ -244,7 +246,7 @@ __global__ __launch_bounds__(256) void k_pyramid(const Geom* __restrict__ g, Fra
                     packed |= ((c0y * h0 + c1y * h1 + 32768u) >> 16) << (8 * i);
                 }
             }
-            *reinterpret_cast<uint32_t*>(dp + (long)r * L.pitch) = packed;
+            *reinterpret_cast<uint32_t*>(lbase + (dofs + (uint32_t)r * (uint32_t)L.pitch)) = packed;
         }
     }
 }
