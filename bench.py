@@ -99,7 +99,7 @@ def main():
     ap.add_argument("--distinct", type=int, default=256, help="distinct seeded pairs generated per GPU (tiled up to --pairs)")
     ap.add_argument("--chunk", type=int, default=32, help="pairs per detect/match launch wave")
     ap.add_argument("--workers", type=int, default=0, help="host processes for input generation (0 = auto; use 1 under rocprofv3)")
-    ap.add_argument("--streams", type=int, default=2,
+    ap.add_argument("--streams", type=int, default=4,
                     help="contexts (one HIP stream and workspace each) driven by one host thread each; the batch is split between them")
     ap.add_argument("--join-steps", action="store_true", help="diagnostic: all contexts finish a step before any starts the next one")
     ap.add_argument("--ba", action="store_true",

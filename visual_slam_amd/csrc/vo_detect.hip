@@ -1377,14 +1377,14 @@ int vo_launch_detect(vo_ctx* c, const FrameSrc& src, int F, hipStream_t st) {
         dim3 grid((L.w + 255) / 256, (L.h + 4 * PYR_ROWS - 1) / (4 * PYR_ROWS), F);   // plain order: the XCD-contiguous order measured 7 % slower here (no inter-block reuse)
         KT(c, st, VO_K_PYRAMID, hipLaunchKernelGGL(k_pyramid, grid, dim3(256), 0, st, dg, src, pyr, (const ResizeCoef*)c->d_rtab.p, l));
     }
-    // The blur only needs the pyramid: outside the timing mode it runs on the context's second stream, next to the
+    // The blur only needs the pyramid: outside the timing mode, and while at most two contexts share the device, it runs on the context's second stream, next to the
     // FAST -> retainBest -> Harris -> retainBest -> orientation chain (whose retainBest replays are latency bound and
     // leave most of the chip idle), and joins before the descriptors.
     BlurK bk;
     gaussian_kernel7_sigma2(bk);
     auto blur_fn = g.blur_mode == 1 ? k_blur<1, false> : (g.fma ? k_blur<0, true> : k_blur<0, false>);
     static const bool serial = getenv("VO_SERIAL") != nullptr;   // profiling aid: one kernel at a time, so trace durations are per kernel
-    const bool fork_blur = !serial && !c->timing && c->debug_stop == 0 && c->aux_stream != nullptr;
+    const bool fork_blur = !serial && !c->timing && c->debug_stop == 0 && c->aux_stream != nullptr && vo_live_contexts(c->device) <= 2;
     if (fork_blur) {
         HIP_TRY(c, hipEventRecord(c->ev_fork, st));
         HIP_TRY(c, hipStreamWaitEvent(c->aux_stream, c->ev_fork, 0));

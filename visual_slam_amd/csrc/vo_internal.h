@@ -86,6 +86,7 @@ struct DevBuf {
 
 struct vo_ctx {
     int device = 0;
+    bool counted = false;   // included in the per-device live-context count
     int max_w = 0, max_h = 0, max_frames = 0, chunk_pairs = 0, max_pairs = 0;
     vo_orb_params params;
     std::string err;
@@ -135,6 +136,7 @@ struct vo_ctx {
     std::vector<int> ev_ids;      // kernel id of each bracketed launch; events 2*i, 2*i+1
 };
 
+int vo_live_contexts(int device);   // contexts alive on the device (all threads of the process)
 void kt_begin(vo_ctx* c, hipStream_t st, int id);
 void kt_end(vo_ctx* c, hipStream_t st);
 int kt_collect(vo_ctx* c);   // after the stream is synchronised
