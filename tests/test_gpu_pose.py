@@ -269,3 +269,32 @@ def test_many_synthetic_pairs_match_oracle(oracle):
         assert rc == r["status"] == 0, seeds[i]
         assert [r["n_kp1"], r["n_kp2"], r["n_match"], r["n_inlier"]] == counts.tolist(), seeds[i]
         assert rot_angle(T[:3, :3], r["T"][:3, :3]) < 1e-6 and dir_angle(T[:3, 3], r["T"][:3, 3]) < 1e-6, seeds[i]
+
+
+def test_device_frames_with_stride_and_odd_base(K02):
+    """vo_pairs_run_device / vo_sequence_run_device read level 0 in place: frames whose rows are `stride` bytes apart
+    (odd, so rows and the base pointer are unaligned) give the records of the dense layout."""
+    import torch
+    from visual_slam_amd import _lib, synth
+    a, b = synth.make_batch(range(3), workers=1)
+    n, h, w = a.shape
+    K = synth.K_KITTI02
+    c = _lib.Context(max_w=w, max_h=h, chunk_pairs=2, max_pairs=n)
+    try:
+        dA = torch.from_numpy(a).cuda(); dB = torch.from_numpy(b).cuda()
+        dense = c.pairs_run_device(dA.data_ptr(), dB.data_ptr(), n, w, h, w, K)
+        stride = w + 2                                        # 1243
+        pa = torch.full((n * h * stride + 7,), 255, dtype=torch.uint8, device="cuda")
+        pb = torch.full((n * h * stride + 7,), 255, dtype=torch.uint8, device="cuda")
+        for src, dst in ((dA, pa), (dB, pb)):
+            dst[1:1 + n * h * stride].view(n, h, stride)[:, :, :w] = src      # base pointer 1 byte past an aligned address
+        strided = c.pairs_run_device(pa.data_ptr() + 1, pb.data_ptr() + 1, n, w, h, stride, K)
+        for f in dense.dtype.names:
+            assert np.array_equal(dense[f], strided[f]), f
+        seq_dense = c.sequence_run_device(dA.data_ptr(), n, w, h, w, K)
+        seq_strided = c.sequence_run_device(pa.data_ptr() + 1, n, w, h, stride, K)
+        for f in seq_dense.dtype.names:
+            assert np.array_equal(seq_dense[f], seq_strided[f]), f
+        assert (dense["status"] == 0).all()
+    finally:
+        c.close()
