@@ -111,7 +111,7 @@ def main():
                     help="extra diagnostic: also time vo_sequence_run_device on the A frames taken as one sequence (each frame extracted once)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo to rehearse several ranks on one GPU)")
     ap.add_argument("--config4", action="store_true",
-                    help="diagnostic: run configs[3] instead (3840x2160 frames, 20000 ORB features; use e.g. --pairs 16 --distinct 4 --chunk 4)")
+                    help="diagnostic: run configs[3] instead (3840x2160 frames, 20000 ORB features; use e.g. --pairs 64 --distinct 4 --chunk 16 --streams 2)")
     args = ap.parse_args()
     global W_IMG, H_IMG, NFEAT
     if args.config4:
