@@ -117,12 +117,23 @@ def main():
     if args.config4:
         W_IMG, H_IMG, NFEAT = 3840, 2160, 20000
 
-    import torch
-    import torch.distributed as dist
-
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+
+    # synthetic input first: the generator forks worker processes, which must happen before this process touches the GPU or RCCL
+    from visual_slam_amd import synth
+    B = args.pairs
+    workers = args.workers if args.workers > 0 else max(1, min(12, (os.cpu_count() or 1) // max(world, 1)))
+    nd = min(B, args.distinct)
+    imgsA, imgsB = synth.make_batch(range(rank * nd, rank * nd + nd), W_IMG, H_IMG, workers=workers)
+    if nd < B:  # tile the distinct pairs up to the batch size (same work per pair, bounded host set-up time)
+        reps = (B + nd - 1) // nd
+        imgsA = np.concatenate([imgsA] * reps)[:B]
+        imgsB = np.concatenate([imgsB] * reps)[:B]
+
+    import torch
+    import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU fallback")
     if args.backend != "nccl":
@@ -139,14 +150,6 @@ def main():
     if args.lib:
         _lib.SO_PATH = os.path.abspath(args.lib)
 
-    B = args.pairs
-    workers = args.workers if args.workers > 0 else max(1, min(12, (os.cpu_count() or 1) // max(world, 1)))
-    nd = min(B, args.distinct)
-    imgsA, imgsB = synth.make_batch(range(rank * nd, rank * nd + nd), W_IMG, H_IMG, workers=workers)
-    if nd < B:  # tile the distinct pairs up to the batch size (same work per pair, bounded host set-up time)
-        reps = (B + nd - 1) // nd
-        imgsA = np.concatenate([imgsA] * reps)[:B]
-        imgsB = np.concatenate([imgsB] * reps)[:B]
     K = synth.config_K(W_IMG, H_IMG)
     dA = torch.from_numpy(imgsA).cuda()
     dB = torch.from_numpy(imgsB).cuda()
