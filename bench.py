@@ -246,11 +246,24 @@ def main():
         f = np.arange(B)
         k = (f // 16) % nd
         dS = torch.where(torch.from_numpy((f % 2 == 0)).cuda()[:, None, None], dA[torch.from_numpy(k).cuda()], dB[torch.from_numpy(k).cuda()]).contiguous()
-        ctx.sequence_run_device(dS.data_ptr(), B, W_IMG, H_IMG, W_IMG, K)
+        # the B-1 pairs are split over the S contexts like the pair batches; neighbouring blocks share one frame
+        sb = [parallel.shard_range(B - 1, i, S) for i in range(S)]
+
+        def seq_part(i, nsteps):
+            lo, hi = sb[i]
+            r = None
+            for _ in range(nsteps):
+                r = ctxs[i].sequence_run_device(dS.data_ptr() + lo * fsz, hi - lo + 1, W_IMG, H_IMG, W_IMG, K)
+            return r
+
+        def seq_run(nsteps):
+            parts = list(pool.map(lambda i: seq_part(i, nsteps), range(S))) if pool else [seq_part(0, nsteps)]
+            return np.concatenate(parts)
+
+        seq_run(1)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        for _ in range(args.steps):
-            r2 = ctx.sequence_run_device(dS.data_ptr(), B, W_IMG, H_IMG, W_IMG, K)
+        r2 = seq_run(args.steps)
         torch.cuda.synchronize()
         seq = {"frame_pairs_per_sec": round((B - 1) * args.steps / (time.perf_counter() - t1), 2), "pairs_ok": int((r2["status"] == 0).sum()),
                "pairs_total": B - 1, "note": "consecutive-pair mode (SURVEY 8(f) N3): B frames, B-1 pairs, each frame extracted once per chunk"}
