@@ -568,9 +568,8 @@ __global__ __launch_bounds__(64) void k_fast_emit(const Geom* __restrict__ g, co
     const uint32_t* tl = tile_list + ((long)f * g->ntiles + t) * VO_TILE_CAP;
     const long cb = (long)f * g->cand_frame + L.cand_ofs;
     for (int e = lane; e < total; e += 64) {
-        int r = 0;
-        while (rowstart[r + 1] <= e) r++;
-        uint32_t p = tl[e];
+        const uint32_t p = tl[e];
+        const int r = UNPACK_Y(p) - (VO_EDGE + td.ty * VO_TILE_H);   // the tile list is in raster order: the row is in the record
         long o = cb + rowofs[r] + (e - rowstart[r]);
         key[o] = (float)UNPACK_S(p);
         payload[o] = p;
