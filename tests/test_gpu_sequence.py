@@ -76,3 +76,26 @@ def test_loader_feeds_sequence_run(kitti02, K02):
     ctx.close()
     got = np.concatenate(got)
     assert _records_equal(got, ref)
+
+
+def test_device_images_from_unsynchronised_torch_op(kitti02, K02):
+    """Stream-ordering contract (include/vo_mi355.h): with stream=NULL the library's private stream waits for the
+    device's default stream, so images still being produced by torch ops when the call is made are read complete."""
+    import torch
+    from visual_slam_amd import _lib
+    imgs = np.stack(kitti02)
+    F, h, w = imgs.shape
+    ctx = _lib.Context(max_w=w, max_h=h, chunk_pairs=2, max_pairs=F - 1)
+    ref = ctx.sequence_run(imgs, K02)
+    src = torch.from_numpy(imgs).cuda()
+    big = torch.zeros((256, h, w), dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    for _ in range(3):
+        d = torch.zeros_like(src)
+        # a long queue of default-stream work ahead of the op that finally produces the frames: no synchronisation
+        for _ in range(40):
+            big = big + 1
+        d.copy_(src.flip(0).flip(0) + (big[:F] - big[:F]))
+        got = ctx.sequence_run_device(d.data_ptr(), F, w, h, w, K02)
+        assert _records_equal(got, ref)
+    ctx.close()

@@ -107,6 +107,7 @@ static int ctx_init(vo_ctx* c) {
     HIP_TRY(c, hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
     HIP_TRY(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
     HIP_TRY(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+    HIP_TRY(c, hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming));
     c->kp_cap = p.nfeatures + 1024;
     const long F = c->max_frames, kc = c->kp_cap, MP = c->max_pairs, CP = c->chunk_pairs;
     // geometry-sized buffers: size them for the largest image with a dry geometry pass
@@ -216,6 +217,7 @@ void vo_ctx_destroy(vo_ctx* c) {
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->ev_in) (void)hipEventDestroy(c->ev_in);
     if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -432,6 +434,16 @@ static int pose_stage(vo_ctx* c, int Pb, const double K[9], vo_pair_result* out,
     return VO_OK;
 }
 
+// Stream-ordering contract of the *_device entry points: with an explicit stream the work is enqueued on it, in order
+// with whatever the caller put there before.  With stream == NULL the work runs on the context's private (non-blocking)
+// stream, which is first made to wait for everything enqueued so far on the device's default stream -- the stream a
+// framework's tensor ops (torch's default stream) produce the images on -- so un-synchronised producers are safe.
+static int order_after_default(vo_ctx* c) {
+    HIP_TRY(c, hipEventRecord(c->ev_in, nullptr));
+    HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_in, 0));
+    return VO_OK;
+}
+
 int vo_pairs_run_device(vo_ctx* c, const uint8_t* imgsA, const uint8_t* imgsB, int B, int w, int h, int stride, const double K[9], double ratio,
                         vo_pair_result* out, void* stream) {
     if (!c) return VO_ERR_INVALID;
@@ -441,6 +453,7 @@ int vo_pairs_run_device(vo_ctx* c, const uint8_t* imgsA, const uint8_t* imgsB, i
     int rc = vo_build_geometry(c, w, h);
     if (rc != VO_OK) return rc;
     hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+    if (!stream) { int rc2 = order_after_default(c); if (rc2 != VO_OK) return rc2; }
     const long fs = (long)stride * h;
     for (int b0 = 0; b0 < B; b0 += c->max_pairs) {
         const int Pb = std::min(c->max_pairs, B - b0);
@@ -475,6 +488,7 @@ int vo_sequence_run_device(vo_ctx* c, const uint8_t* imgs, int F, int w, int h, 
     int rc = vo_build_geometry(c, w, h);
     if (rc != VO_OK) return rc;
     hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+    if (!stream) { int rc2 = order_after_default(c); if (rc2 != VO_OK) return rc2; }
     const long fs = (long)stride * h;
     const int B = F - 1;
     // a chunk of Pc pairs needs Pc+1 frames of the 2*chunk_pairs-frame workspace and Pc rows of the match workspace

@@ -93,6 +93,7 @@ struct vo_ctx {
     hipStream_t stream = nullptr;  // own stream for the host-pointer entry points
     hipStream_t aux_stream = nullptr;            // second stream: the blur runs beside the keypoint chain
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_in = nullptr;                  // orders the private stream after the default stream (stream == NULL calls)
 
     // geometry currently built (w,h) and its device copies
     Geom geom;
