@@ -89,6 +89,21 @@ int vo_match_knn2_ratio(vo_ctx* ctx, const uint8_t* q, int nq, const uint8_t* t,
 int vo_match_knn2(vo_ctx* ctx, const uint8_t* q, int nq, const uint8_t* t, int nt,
                   int32_t* idx1, int32_t* d1, int32_t* idx2, int32_t* d2);
 
+/* The matcher for callers that cannot allocate (code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc).  It has NO counterpart in the reference: it is vo_match_knn2_ratio
+ * with device pointers in and out, and with the kernels' workspace (staged descriptors, per-segment
+ * best/second keys, compacted rows, counters: 458,880 bytes) in a file-scope device array instead of
+ * the context's buffers; its address on the context's GPU is resolved once, in vo_ctx_create.
+ * q_dev [nq][32], t_dev [nt][32]: device memory.  matches_dev: device int32 [cap][4] = queryIdx,
+ * trainIdx, d1, d2 of the kept matches in ascending queryIdx; *n_dev (device int32) receives their
+ * number, rows at or beyond cap are not written.  nq, nt <= VO_NOALLOC_MAX_DESC, else VO_ERR_CAPACITY.
+ * The work is enqueued on `stream` (hipStream_t; NULL = the default stream) and the call returns
+ * without synchronising; it calls no hipMalloc / hipFree / allocating routine.  All calls on one GPU
+ * share that GPU's array: calls that overlap on one GPU (two streams, two threads) race. */
+#define VO_NOALLOC_MAX_DESC 4096
+int vo_match_knn2_ratio_noalloc(vo_ctx* ctx, const uint8_t* q_dev, int nq, const uint8_t* t_dev, int nt, double ratio,
+                                int32_t* matches_dev, int cap, int32_t* n_dev, void* stream);
+
 /* Replaces cv2.findEssentialMat(q1, q2, K, cv2.RANSAC, prob, thr, maxIters),
  * libs/vo_utils.py:141.  q1,q2: host float32 [n][2]; K row-major; E row-major; mask [n]. */
 int vo_find_essential_ransac(vo_ctx* ctx, const float* q1, const float* q2, int n, const double K[9],

@@ -35,7 +35,7 @@ PAIR_DTYPE = np.dtype([("T", "<f8", (4, 4)), ("n_kp1", "<i4"), ("n_kp2", "<i4"),
 EXPORTS = [
     "vo_default_orb_params", "vo_ctx_create", "vo_ctx_destroy", "vo_last_error", "vo_orb_detect_compute", "vo_match_knn2_ratio",
     "vo_match_knn2", "vo_find_essential_ransac", "vo_recover_pose", "vo_triangulate", "vo_pairs_run_device", "vo_pairs_run", "vo_sequence_run_device", "vo_sequence_run", "vo_ba_plan_create", "vo_ba_plan_destroy", "vo_ba_pass_device", "vo_ba_pass",
-    "vo_debug_read", "vo_set_debug_stop", "vo_set_kernel_timing", "vo_get_kernel_timing",
+    "vo_match_knn2_ratio_noalloc", "vo_debug_read", "vo_set_debug_stop", "vo_set_kernel_timing", "vo_get_kernel_timing",
 ]
 
 _lib = None
@@ -66,6 +66,7 @@ def load():
     lib.vo_orb_detect_compute.argtypes = [vp, vp, i, i, i, vp, vp, i, vp]
     lib.vo_match_knn2_ratio.argtypes = [vp, vp, i, vp, i, d, vp, vp, vp, vp, i, vp]
     lib.vo_match_knn2.argtypes = [vp, vp, i, vp, i, vp, vp, vp, vp]
+    lib.vo_match_knn2_ratio_noalloc.argtypes = [vp, vp, i, vp, i, d, vp, i, vp, vp]
     lib.vo_find_essential_ransac.argtypes = [vp, vp, vp, i, vp, d, d, i, vp, vp, vp]
     lib.vo_recover_pose.argtypes = [vp, vp, vp, vp, i, vp, d, vp, vp, vp]
     lib.vo_triangulate.argtypes = [vp, vp, vp, vp, vp, i, vp]
@@ -160,6 +161,12 @@ class Context:
         n = C.c_int(0)
         self._check(self.lib.vo_match_knn2_ratio(self.h, _ptr(q), len(q), _ptr(t), len(t), float(ratio), *[_ptr(o) for o in out], cap, C.byref(n)))
         return tuple(o[: n.value].copy() for o in out)  # queryIdx, trainIdx, d1, d2
+
+    def match_knn2_ratio_noalloc(self, q_ptr, nq, t_ptr, nt, out_ptr, cap, n_ptr, ratio=0.45, stream=None):
+        """Device pointers in and out; enqueues on `stream` (None = default stream) and returns without synchronising.
+        Allocates nothing (include/vo_mi355.h: vo_match_knn2_ratio_noalloc)."""
+        self._check(self.lib.vo_match_knn2_ratio_noalloc(self.h, C.c_void_p(q_ptr), nq, C.c_void_p(t_ptr), nt, float(ratio), C.c_void_p(out_ptr), cap,
+                                                         C.c_void_p(n_ptr), C.c_void_p(stream) if stream else None))
 
     def find_essential_ransac(self, q1, q2, K, prob=0.999, thr=1.0, max_iters=1000):
         q1 = np.ascontiguousarray(q1, np.float32).reshape(-1, 2)

@@ -175,7 +175,8 @@ static int ctx_init(vo_ctx* c) {
     HIP_TRY(c, hipMemset(c->d_frame_status.p, 0, c->d_frame_status.bytes));
     HIP_TRY(c, hipMemset(c->d_pair_status.p, 0, c->d_pair_status.bytes));
     HIP_TRY(c, hipMemset(c->d_kp.p, 0, c->d_kp.bytes));
-    return VO_OK;
+    c->err.reserve(256);       // error messages after this point do not touch the heap
+    return vo_noalloc_init(c);
 }
 
 int vo_ctx_create(int device, int max_w, int max_h, int chunk_pairs, int max_pairs, const vo_orb_params* params, vo_ctx** out) {

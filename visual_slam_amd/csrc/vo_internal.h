@@ -157,6 +157,7 @@ int vo_launch_detect(vo_ctx* c, const FrameSrc& src, int F, hipStream_t st);
 // match.hip
 int vo_match_segments(int kp_cap);   // train-set segments per pair (rows of d_match)
 int vo_launch_match_impl(vo_ctx* c, int P, int nA, double ratio, int pair0, int4* raw_out, hipStream_t st);
+int vo_noalloc_init(vo_ctx* c);      // resolves this device's copy of the no-allocation scratch array (once per device)
 // pose.hip
 struct PoseK { double fx, fy, cx, cy; };
 // RANSAC (findEssentialMat) for pairs [0,P) of the pair arrays; E/mask/n_inlier left in d_pose / d_mask

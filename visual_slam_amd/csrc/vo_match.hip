@@ -236,9 +236,11 @@ __global__ __launch_bounds__(1024) void k_ratio(const uint2* __restrict__ seg_be
             const int ti = (int)(k1 & 0xFFFF);
             const long ob = gp * kp_cap + o;
             mq[ob] = make_int4(q, ti, (int)(k1 >> 16), (int)(k2 >> 16));
-            const vo_keypoint ka = kps[(long)qf * kp_cap + q], kb = kps[(long)tf * kp_cap + ti];
-            q1[ob] = make_float2(ka.x, ka.y);
-            q2[ob] = make_float2(kb.x, kb.y);
+            if (kps) {   // uniform; null for the descriptor-only entry point (vo_match_knn2_ratio_noalloc)
+                const vo_keypoint ka = kps[(long)qf * kp_cap + q], kb = kps[(long)tf * kp_cap + ti];
+                q1[ob] = make_float2(ka.x, ka.y);
+                q2[ob] = make_float2(kb.x, kb.y);
+            }
         }
         __syncthreads();
         if (tid == 0) s_running = running + tot;
@@ -259,6 +261,74 @@ int vo_launch_match_impl(vo_ctx* c, int P, int nA, double ratio, int pair0, int4
     KT(c, st, VO_K_RATIO, hipLaunchKernelGGL(k_ratio, dim3(P), dim3(1024), 0, st, (const uint2*)c->d_match.p, nseg, (const int*)c->d_nkp.p, kp_cap, nA,
                        (const vo_keypoint*)c->d_kp.p, ratio, pair0, (int4*)c->d_mq.p, (float2*)c->d_q1.p, (float2*)c->d_q2.p,
                        (int*)c->d_nmatch.p, (int*)c->d_pair_status.p, (int2*)c->d_pair_nkp.p, (const int*)c->d_frame_status.p, raw_out));
+    HIP_TRY(c, hipGetLastError());
+    return VO_OK;
+}
+
+// ------------------------------------------------------------------ the entry point that allocates nothing
+// vo_match_knn2_ratio_noalloc (include/vo_mi355.h): k_match + k_ratio with their workspace (the staged descriptors,
+// the per-segment best/second keys, the compacted match rows and a few counters) in ONE file-scope device array
+// instead of the context's hipMalloc'ed buffers.  Each GPU holds its own copy of the array at its own address:
+// vo_noalloc_init (from vo_ctx_create, with the context's device current) asks the runtime for that address once per
+// device; host code only ever uses that pointer -- the array's name is a host-side stand-in, not a device address.
+#define NA_CAP VO_NOALLOC_MAX_DESC
+#define NA_NSEG 4                                             // vo_match_segments(NA_CAP): 4 x 1024 trains
+#define NA_OFF_DESC 0L                                        // uint8 [2][NA_CAP][32]: query frame, train frame
+#define NA_OFF_SEG (NA_OFF_DESC + 2L * NA_CAP * 32)           // uint2 [NA_NSEG][NA_CAP]
+#define NA_OFF_MQ (NA_OFF_SEG + (long)NA_NSEG * NA_CAP * 8)   // int4 [NA_CAP]
+#define NA_OFF_SMALL (NA_OFF_MQ + (long)NA_CAP * 16)          // int nkp[2], frame_status[2], nmatch, pair_status, pair_nkp[2]
+#define NA_BYTES (NA_OFF_SMALL + 256)
+static __device__ __align__(256) unsigned char scratch[NA_BYTES];   // 458,880 B per GPU, held until the process ends
+static void* g_scratch_ptr[64];                                     // per device: the address of ITS copy of `scratch`
+
+int vo_noalloc_init(vo_ctx* c) {
+    if (c->device < 0 || c->device >= 64) return VO_OK;   // such a context reports the missing set-up at the call
+    if (g_scratch_ptr[c->device]) return VO_OK;
+    void* p = nullptr;
+    HIP_TRY(c, hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+    g_scratch_ptr[c->device] = p;
+    return VO_OK;
+}
+
+__global__ void k_noalloc_setup(int* __restrict__ small, int nq, int nt) {
+    if (threadIdx.x == 0) {
+        small[0] = nq; small[1] = nt;    // nkp of the query / train frame
+        small[2] = 0; small[3] = 0;      // frame_status
+        small[4] = 0; small[5] = 0;      // nmatch, pair_status (k_ratio writes both)
+    }
+}
+
+__global__ void k_noalloc_out(const int4* __restrict__ mq, const int* __restrict__ small, int cap, int4* __restrict__ matches, int* __restrict__ n_out) {
+    const int n = small[4];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) *n_out = n;
+    if (i < n && i < cap) matches[i] = mq[i];
+}
+
+extern "C" int vo_match_knn2_ratio_noalloc(vo_ctx* c, const uint8_t* q_dev, int nq, const uint8_t* t_dev, int nt, double ratio,
+                                           int32_t* matches_dev, int cap, int32_t* n_dev, void* stream) {
+    if (!c) return VO_ERR_INVALID;
+    if (!q_dev || !t_dev || !n_dev || nq < 0 || nt < 0 || cap < 0 || (cap > 0 && !matches_dev))
+        return vo_fail(c, VO_ERR_INVALID, "vo_match_knn2_ratio_noalloc: bad arguments");
+    if (nq > NA_CAP || nt > NA_CAP)
+        return vo_fail(c, VO_ERR_CAPACITY, "vo_match_knn2_ratio_noalloc: more than VO_NOALLOC_MAX_DESC (4096) descriptors in a set");
+    if (nt < 2) return vo_fail(c, VO_ERR_TOO_FEW, "knnMatch(k=2) needs at least 2 train descriptors");
+    if (c->device < 0 || c->device >= 64 || !g_scratch_ptr[c->device])
+        return vo_fail(c, VO_ERR_HIP, "vo_match_knn2_ratio_noalloc: the device's scratch address was not resolved at vo_ctx_create");
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t st = (hipStream_t)stream;
+    uint8_t* base = (uint8_t*)g_scratch_ptr[c->device];
+    uint8_t* desc = base + NA_OFF_DESC;
+    uint2* seg = (uint2*)(base + NA_OFF_SEG);
+    int4* mq = (int4*)(base + NA_OFF_MQ);
+    int* small = (int*)(base + NA_OFF_SMALL);
+    hipLaunchKernelGGL(k_noalloc_setup, dim3(1), dim3(64), 0, st, small, nq, nt);
+    if (nq) HIP_TRY(c, hipMemcpyAsync(desc, q_dev, (size_t)nq * 32, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(c, hipMemcpyAsync(desc + (long)NA_CAP * 32, t_dev, (size_t)nt * 32, hipMemcpyDeviceToDevice, st));
+    hipLaunchKernelGGL(k_match<3>, dim3((NA_CAP + 383) / 384, NA_NSEG, 1), dim3(256), 0, st, (const uint8_t*)desc, (const int*)small, NA_CAP, 1, NA_NSEG, seg);
+    hipLaunchKernelGGL(k_ratio, dim3(1), dim3(1024), 0, st, (const uint2*)seg, NA_NSEG, (const int*)small, NA_CAP, 1, (const vo_keypoint*)nullptr, ratio, 0, mq,
+                       (float2*)nullptr, (float2*)nullptr, small + 4, small + 5, (int2*)(small + 6), (const int*)(small + 2), (int4*)nullptr);
+    hipLaunchKernelGGL(k_noalloc_out, dim3((NA_CAP + 255) / 256), dim3(256), 0, st, (const int4*)mq, (const int*)small, cap, (int4*)matches_dev, (int*)n_dev);
     HIP_TRY(c, hipGetLastError());
     return VO_OK;
 }
