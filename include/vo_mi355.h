@@ -39,8 +39,12 @@ typedef struct {
     int32_t edge_threshold; /* 31 (fixed) */
     int32_t patch_size;     /* 31 (fixed) */
     int32_t fast_threshold; /* 20 */
-    int32_t blur_mode;      /* 0: float sepFilter2D kernel (default), 1: int32 kernel x256 */
-    int32_t fma;            /* 1: fastAtan2 / float blur contract to fma (default), 0: not */
+    /* Variants of recalled OpenCV 4.8.0 behaviour that no fixture of the reference pins (SURVEY.md
+     * App. A "[L]" items): each is switchable on its own, defaults first. */
+    int32_t blur_mode;      /* A.1.7: 0 float sepFilter2D kernel (default), 1 int32 kernel x256 */
+    int32_t fma_atan;       /* A.1.6: 1 fastAtan2's polynomial contracts to fma (AVX2+FMA3 dispatch, default), 0 not */
+    int32_t fma_blur;       /* A.1.7: 1 the float blur's a*b+c contract to fma (default), 0 not */
+    int32_t trig_mode;      /* A.1.8: 0 (float)cos((double)angle) (default), 1 glibc cosf/sinf (the float overloads) */
 } vo_orb_params;
 
 /* cv::KeyPoint without class_id (always -1). */

@@ -23,7 +23,9 @@ class OrbParams(C.Structure):
         ("patch_size", C.c_int32),
         ("fast_threshold", C.c_int32),
         ("blur_mode", C.c_int32),
-        ("fma", C.c_int32),
+        ("fma_atan", C.c_int32),
+        ("fma_blur", C.c_int32),
+        ("trig_mode", C.c_int32),
     ]
 
 

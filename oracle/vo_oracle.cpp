@@ -353,10 +353,12 @@ void gaussian_blur7(const uint8_t* src, int w, int h, int sstride, uint8_t* dst,
 }
 
 /* ---------------------------------------------------------------- rBRIEF (A.1.8) */
-void orb_descriptor(const uint8_t* img, int stride, int cx, int cy, float angle_deg, uint8_t desc[32]) {
+void orb_descriptor(const uint8_t* img, int stride, int cx, int cy, float angle_deg, uint8_t desc[32], int trig_mode) {
     float angle = angle_deg;
     angle *= (float)(M_PI / 180.f);
-    float a = (float)std::cos((double)angle), b = (float)std::sin((double)angle);
+    float a, b;
+    if (trig_mode == 1) { a = cosf(angle); b = sinf(angle); }      /* the float overloads: this host's libm itself */
+    else { a = (float)std::cos((double)angle); b = (float)std::sin((double)angle); }
     const uint8_t* center = img + (size_t)cy * stride + cx;
     const signed char* pat = VO_ORB_PATTERN_31;
     for (int i = 0; i < 32; i++) {
@@ -844,7 +846,9 @@ void orc_default_orb_params(orc_orb_params* p) {
     p->patch_size = 31;
     p->fast_threshold = 20;
     p->blur_mode = 0;
-    p->fma = 1;
+    p->fma_atan = 1;
+    p->fma_blur = 1;
+    p->trig_mode = 0;
 }
 
 void orc_level_geometry(int w, int h, const orc_orb_params* p, int* lw, int* lh, float* scale, int* quota) {
@@ -908,10 +912,10 @@ int orc_orb_detect_compute(const uint8_t* img, int w, int h, int stride, const o
         if (dbg && dbg->sel2_count) dbg->sel2_count[l] = (int)kp.size();
         kept.insert(kept.end(), kp.begin(), kp.end());
     }
-    for (auto& k : kept) k.angle = ic_angle(&pyr[g.ofs[k.octave]], g.w[k.octave], cvRoundF(k.x), cvRoundF(k.y), p->fma != 0);
+    for (auto& k : kept) k.angle = ic_angle(&pyr[g.ofs[k.octave]], g.w[k.octave], cvRoundF(k.x), cvRoundF(k.y), p->fma_atan != 0);
     /* blur every level, then describe */
     for (int l = 0; l < g.nlevels; l++)
-        gaussian_blur7(&pyr[g.ofs[l]], g.w[l], g.h[l], g.w[l], &blurred[g.ofs[l]], g.w[l], p->blur_mode, p->fma != 0);
+        gaussian_blur7(&pyr[g.ofs[l]], g.w[l], g.h[l], g.w[l], &blurred[g.ofs[l]], g.w[l], p->blur_mode, p->fma_blur != 0);
     if (dbg && dbg->pyr) std::memcpy(dbg->pyr, pyr.data(), g.total);
     if (dbg && dbg->blurred) std::memcpy(dbg->blurred, blurred.data(), g.total);
     *n = (int)kept.size();
@@ -930,7 +934,7 @@ int orc_orb_detect_compute(const uint8_t* img, int w, int h, int stride, const o
         if (desc) {
             float s = 1.f / sc;
             int cx = cvRoundF(o.x * s), cy = cvRoundF(o.y * s);
-            orb_descriptor(&blurred[g.ofs[k.octave]], g.w[k.octave], cx, cy, k.angle, desc + i * 32);
+            orb_descriptor(&blurred[g.ofs[k.octave]], g.w[k.octave], cx, cy, k.angle, desc + i * 32, p->trig_mode);
         }
     }
     return 0;

@@ -45,9 +45,11 @@ typedef struct {
     int32_t fast_threshold;  /* 20 */
     int32_t blur_mode;       /* 0: sepFilter2D float kernel (OpenCV >= 4.5 path, default)
                                 1: int32 kernel [18,34,49,55,49,34,18]>>16 */
-    int32_t fma;             /* 1: fastAtan2 and the float blur contract a*b+c to fma, as an
-                                   AVX2+FMA3-dispatched x86 build of OpenCV does (default)
-                                0: separate multiply and add */
+    int32_t fma_atan;        /* 1: fastAtan2 contracts a*b+c to fma, as the AVX2+FMA3-dispatched
+                                   mathfuncs_core of an x86 build does (default); 0: separate mul, add */
+    int32_t fma_blur;        /* the same choice for the float sepFilter2D blur (another translation unit) */
+    int32_t trig_mode;       /* descriptor rotation: 0 (float)cos((double)angle) (default);
+                                1 the float overloads = this host's libm cosf / sinf */
 } orc_orb_params;
 
 void orc_default_orb_params(orc_orb_params* p);

@@ -82,3 +82,17 @@ def test_synthetic_generator_is_seeded():
     a3, *_ = synth.make_pair(4, 320, 200)
     assert not np.array_equal(a1, a3)
     assert abs(np.linalg.norm(t) - 1) < 1e-12 and abs(np.linalg.det(R) - 1) < 1e-12
+
+
+def test_orb_pattern_table_hash():
+    """include/vo_orb_pattern_31.h is shared by the product and the oracle, so a typo in it would pass every GPU-vs-oracle
+    test: pin the 1024 values to the sha256 its header quotes (the scikit-image / Rublee et al. table)."""
+    import hashlib
+    import re
+    src = open(os.path.join(ROOT, "include", "vo_orb_pattern_31.h")).read()
+    quoted = re.search(r"\b([0-9a-f]{64})\b", src).group(1)
+    body = src[src.index("{", src.index("VO_ORB_PATTERN_31[")) + 1: src.rindex("}")]
+    vals = np.array([int(v) for v in re.findall(r"-?\d+", body)], np.int8)
+    assert vals.shape == (1024,)
+    assert vals[:4].tolist() == [8, -3, 9, 5] and vals[-4:].tolist() == [-1, -6, 0, -11]
+    assert hashlib.sha256(vals.tobytes()).hexdigest() == quoted == "2164181aea6ff9ac426ca512d5130d15e1f6e3cd47b1cbdd568bbe1e55d49023"

@@ -59,12 +59,18 @@ def test_detect_stages_bit_exact(ctx, oracle, kitti02, kitti09, which):
     assert np.array_equal(desc, desc_o)
 
 
-@pytest.mark.parametrize("mode,fma", [(0, 0), (1, 0), (1, 1)])
-def test_blur_and_fma_variants(oracle, kitti02, mode, fma):
+# every switchable variant of recalled OpenCV behaviour (SURVEY.md App. A "[L]" items), each on its own and combined:
+# (blur_mode, fma_atan, fma_blur, trig_mode); the default (0, 1, 1, 0) is what every other test runs
+VARIANTS = [(0, 0, 0, 0), (0, 0, 1, 0), (0, 1, 0, 0), (1, 0, 0, 0), (1, 1, 1, 0), (0, 1, 1, 1), (1, 0, 1, 1), (0, 0, 0, 1)]
+
+
+@pytest.mark.parametrize("mode,fma_atan,fma_blur,trig", VARIANTS)
+def test_blur_fma_and_trig_variants(oracle, kitti02, mode, fma_atan, fma_blur, trig):
     from visual_slam_amd import _lib
-    c = _lib.Context(max_w=1241, max_h=376, blur_mode=mode, fma=fma)
+    v = dict(blur_mode=mode, fma_atan=fma_atan, fma_blur=fma_blur, trig_mode=trig)
+    c = _lib.Context(max_w=1241, max_h=376, **v)
     kps, desc = c.orb_detect_compute(kitti02[2])
-    kps_o, desc_o = oracle.orb_detect_compute(kitti02[2], oracle.default_params(blur_mode=mode, fma=fma))
+    kps_o, desc_o = oracle.orb_detect_compute(kitti02[2], oracle.default_params(**v))
     c.close()
     assert np.array_equal(kps.view(np.uint8), kps_o.view(np.uint8))
     assert np.array_equal(desc, desc_o)

@@ -148,7 +148,7 @@ def test_blur_modes(oracle, kitti02):
     g = np.exp(-x * x / 8.0); g /= g.sum()
     ref = correlate1d(correlate1d(img.astype(np.float64), g, axis=1, mode="mirror"), g, axis=0, mode="mirror")
     for mode, fma, tol in [(0, 1, 0.51), (0, 0, 0.51), (1, 0, 1.1)]:
-        p = oracle.default_params(nlevels=1, blur_mode=mode, fma=fma)
+        p = oracle.default_params(nlevels=1, blur_mode=mode, fma_blur=fma)
         _, _, dump = oracle.orb_detect_compute(img, p, debug=True)
         b = dump["blurred"].reshape(img.shape).astype(np.float64)
         # the x256 integer kernel sums to 257, i.e. a gain of (257/256)^2

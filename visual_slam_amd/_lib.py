@@ -23,7 +23,8 @@ KERNEL_NAMES = ["k_pyramid", "k_fast_tiles", "k_fast_scan", "k_fast_emit", "k_se
 class OrbParams(C.Structure):
     _fields_ = [
         ("nfeatures", C.c_int32), ("scale_factor", C.c_float), ("nlevels", C.c_int32), ("edge_threshold", C.c_int32),
-        ("patch_size", C.c_int32), ("fast_threshold", C.c_int32), ("blur_mode", C.c_int32), ("fma", C.c_int32),
+        ("patch_size", C.c_int32), ("fast_threshold", C.c_int32), ("blur_mode", C.c_int32), ("fma_atan", C.c_int32),
+        ("fma_blur", C.c_int32), ("trig_mode", C.c_int32),
     ]
 
 

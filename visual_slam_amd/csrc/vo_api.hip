@@ -97,7 +97,9 @@ void vo_default_orb_params(vo_orb_params* p) {
     p->patch_size = 31;
     p->fast_threshold = 20;
     p->blur_mode = 0;
-    p->fma = 1;
+    p->fma_atan = 1;
+    p->fma_blur = 1;
+    p->trig_mode = 0;
 }
 
 static int ctx_init(vo_ctx* c) {
@@ -191,7 +193,7 @@ int vo_ctx_create(int device, int max_w, int max_h, int chunk_pairs, int max_pai
     if (max_w < 64 || max_h < 64 || max_w > 4095 || max_h > 4095 || chunk_pairs < 1 || max_pairs < 1 || chunk_pairs > 16384)
         return vo_fail(c, VO_ERR_INVALID, "vo_ctx_create: size arguments out of range");
     if (p.nlevels < 1 || p.nlevels > VO_MAX_LEVELS || p.patch_size != 31 || p.edge_threshold != 31 || p.nfeatures < 1 || p.nfeatures > 60000 ||
-        p.fast_threshold < 1 || p.fast_threshold > 254 || (p.blur_mode != 0 && p.blur_mode != 1))
+        p.fast_threshold < 1 || p.fast_threshold > 254 || (p.blur_mode != 0 && p.blur_mode != 1) || (p.trig_mode != 0 && p.trig_mode != 1))
         return vo_fail(c, VO_ERR_INVALID, "vo_ctx_create: unsupported ORB parameters");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= device || device < 0)

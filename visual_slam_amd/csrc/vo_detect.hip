@@ -24,6 +24,7 @@
 #include <cstdlib>
 #include <cstring>
 
+#include "../../include/vo_sincosf.h"
 #include "vo_internal.h"
 
 // ------------------------------------------------------------------ XCD-aware block order
@@ -78,7 +79,7 @@ int vo_build_geometry(vo_ctx* c, int w, int h) {
     Geom g;
     memset(&g, 0, sizeof(g));
     g.nlevels = p.nlevels; g.w = w; g.h = h;
-    g.fast_threshold = p.fast_threshold; g.blur_mode = p.blur_mode; g.fma = p.fma;
+    g.fast_threshold = p.fast_threshold; g.blur_mode = p.blur_mode; g.fma_atan = p.fma_atan; g.fma_blur = p.fma_blur; g.trig_mode = p.trig_mode;
     const double scaleFactor = (double)p.scale_factor;
     long pyr_ofs = 0, blur_ofs = 0, cand_ofs = 0;
     int tile_base = 0, seg_base = 0, btile_base = 0, rt = 0;
@@ -1043,7 +1044,7 @@ __global__ __launch_bounds__(256) void k_orient(const Geom* __restrict__ g, Fram
             k.x = (float)x0 * L.scale;
             k.y = (float)y0 * L.scale;
             k.size = 31 * L.scale;
-            k.angle = fast_atan2_deg((float)s_m01[threadIdx.x], (float)s_m10[threadIdx.x], g->fma != 0);
+            k.angle = fast_atan2_deg((float)s_m01[threadIdx.x], (float)s_m10[threadIdx.x], g->fma_atan != 0);
             k.response = key[cb + i];
             k.octave = l;
             const long o = (long)f * g->kp_cap + off + i;
@@ -1076,7 +1077,7 @@ static_assert(VO_BLUR_TH == 16 * BL_RPL && VO_BLUR_TW == 64 && BL_ROWS % 14 == 0
 // BL_RPL consecutive rows from BL_RPL+6 float4 rows held in registers (every row-pass value is read
 // from LDS 2.5 times instead of 7) and stores BL_RPL dwords.  The multiply/add order is
 // sepFilter2D's.
-// MODE (blur_mode) and FMA (vo_orb_params.fma) are template parameters: as run-time flags they left a branch per output pixel.
+// MODE (blur_mode) and FMA (vo_orb_params.fma_blur) are template parameters: as run-time flags they left a branch per output pixel.
 template <int MODE, bool FMA>
 __global__ __launch_bounds__(256) void k_blur(const Geom* __restrict__ g, FrameSrc src, const uint8_t* __restrict__ pyr,
                                               uint8_t* __restrict__ blur, const TileDesc* __restrict__ btiles, BlurK bk, int nframes) {
@@ -1268,8 +1269,13 @@ __global__ __launch_bounds__(256) void k_rbrief(const Geom* __restrict__ g, cons
     if (tid < RB_KPB && k0 + tid < n) {
         float angle = kps[(long)f * g->kp_cap + k0 + tid].angle;
         angle *= (float)(M_PI / 180.f);
-        s_cos[tid] = (float)cos((double)angle);
-        s_sin[tid] = (float)sin((double)angle);
+        if (g->trig_mode == 1) {   // the float overloads: glibc's cosf / sinf, restated (include/vo_sincosf.h)
+            s_cos[tid] = vo_glibc_cosf(angle);
+            s_sin[tid] = vo_glibc_sinf(angle);
+        } else {
+            s_cos[tid] = (float)cos((double)angle);
+            s_sin[tid] = (float)sin((double)angle);
+        }
     }
     if (tid >= 64 && tid < 64 + VO_MAX_LEVELS) {
         s_pitch[tid - 64] = g->lv[tid - 64].bpitch;
@@ -1381,7 +1387,7 @@ int vo_launch_detect(vo_ctx* c, const FrameSrc& src, int F, hipStream_t st) {
     // leave most of the chip idle), and joins before the descriptors.
     BlurK bk;
     gaussian_kernel7_sigma2(bk);
-    auto blur_fn = g.blur_mode == 1 ? k_blur<1, false> : (g.fma ? k_blur<0, true> : k_blur<0, false>);
+    auto blur_fn = g.blur_mode == 1 ? k_blur<1, false> : (g.fma_blur ? k_blur<0, true> : k_blur<0, false>);
     static const bool serial = getenv("VO_SERIAL") != nullptr;   // profiling aid: one kernel at a time, so trace durations are per kernel
     const bool fork_blur = !serial && !c->timing && c->debug_stop == 0 && c->aux_stream != nullptr && vo_live_contexts(c->device) <= 2;
     if (fork_blur) {

@@ -41,7 +41,7 @@ struct Geom {
     long blur_frame;        // bytes per frame in the blurred slab
     long cand_frame;        // candidate elements per frame
     int kp_cap;             // keypoints per frame (capacity)
-    int fast_threshold, blur_mode, fma;
+    int fast_threshold, blur_mode, fma_atan, fma_blur, trig_mode;
     LevelGeom lv[VO_MAX_LEVELS];
 };
 

@@ -779,7 +779,7 @@ int vo_launch_ransac(vo_ctx* c, int P, const double K[9], double prob, double th
     hipLaunchKernelGGL(k_ransac_init, dim3(pb), dim3(64), 0, st, pw, nmatch, (const int*)c->d_pair_status.p, P, max_iters);
     // The first round is small: with the usual inlier ratios the adaptive iteration count drops below it
     // after the first good model, and a small round packs several pairs into one solver wavefront.
-    static const int first_round = getenv("VO_RANSAC_FIRST") ? atoi(getenv("VO_RANSAC_FIRST")) : 16;
+    const int first_round = 16;   // a power of two <= VO_HYP_ROUND (k_ransac_solve packs DK_T / nh pairs per wavefront)
     int iters_done = 0;
     for (int round = 0; iters_done < std::max(max_iters, 1); round++) {
         const int nh = round == 0 ? first_round : VO_HYP_ROUND;
