@@ -254,9 +254,13 @@ def main():
     ap.add_argument("--distinct", type=int, default=0,
                     help="diagnostic: generate only this many distinct seeded pairs per rank and tile them (0 = every pair its own seed, as configs[2] says)")
     ap.add_argument("--chunk", type=int, default=32, help="pairs per detect/match launch wave")
+    ap.add_argument("--pose-batch", type=int, default=0,
+                    help="pairs per pose-stage wave (vo_ctx_create max_pairs; 0 = the context's whole share).  Smaller waves overlap the pose stage "
+                         "of one wave with detect + match of the next inside a context: measured 2-7 %% SLOWER than one wave at the end (DESIGN.md 3.2)")
     ap.add_argument("--workers", type=int, default=0, help="host processes for input generation (0 = auto; use 1 under rocprofv3)")
-    ap.add_argument("--streams", type=int, default=4,
-                    help="contexts (one HIP stream and workspace each) driven by one host thread each; the rank's shard is split between them")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="contexts per GPU, each driven by one host thread.  One is enough since round 2: a context spreads its chunks over "
+                         "up to 4 internal lanes (workspace + stream each) by itself; more contexts are a diagnostic")
     ap.add_argument("--join-steps", action="store_true", help="diagnostic: all contexts finish a step before any starts the next one")
     ap.add_argument("--ba", action="store_true",
                     help="extra diagnostic: time the BA residual/Jacobian pass of configs[4] (1000 poses x 200k points x 5 obs, points "
@@ -326,7 +330,7 @@ def main():
     torch.cuda.synchronize()
     S = max(1, min(args.streams, B))
     bounds = [parallel.shard_range(B, i, S) for i in range(S)]
-    ctxs = [_lib.Context(max_w=W_IMG, max_h=H_IMG, chunk_pairs=min(args.chunk, b1 - b0), max_pairs=b1 - b0, device=local_rank, nfeatures=NFEAT) for b0, b1 in bounds]
+    ctxs = [_lib.Context(max_w=W_IMG, max_h=H_IMG, chunk_pairs=min(args.chunk, b1 - b0), max_pairs=(b1 - b0) if args.pose_batch <= 0 else max(1, min(args.pose_batch, b1 - b0)), device=local_rank, nfeatures=NFEAT) for b0, b1 in bounds]
     ctx = ctxs[0]
     fsz = W_IMG * H_IMG
     pool = None
@@ -595,7 +599,7 @@ def main():
             "dtype": "u8/int32 detect+match, f64 pose", "data": "synthetic",
             "config": {"workload": ("configs[2]: batch of 4096 synthetic 1241x376 pairs (configs[1] generator, seed = pair index), 3000 ORB features, 8 levels" if not args.config4 else
                                     "configs[3] (diagnostic): synthetic 3840x2160 pairs, 20000 ORB features, 8 levels"),
-                       "global_pairs": G, "pairs_on_rank0": B, "distinct_pairs_on_rank0": nd, "chunk_pairs": min(args.chunk, B), "streams_per_gpu": S,
+                       "global_pairs": G, "pairs_on_rank0": B, "distinct_pairs_on_rank0": nd, "chunk_pairs": min(args.chunk, B), "pose_batch_pairs": B if args.pose_batch <= 0 else min(args.pose_batch, B), "lanes_per_context": int(os.environ.get("VO_LANES", "4")), "streams_per_gpu": S,
                        "contexts_join_every_step": bool(args.join_steps), "parallelism": "pairs sharded contiguously over ranks, no data-path collective; all_gather of 152-byte records per step",
                        "pairs_ok": ok, "pairs_total": int(len(res)), "timed_region_s": round(dt, 3), "input_generation_s": round(t_gen, 1)},
             "roofline": roofline, "cpu_baseline": cpu, "h2d": h2d, "png_decode": png, "latency": latency, "kitti": kitti,

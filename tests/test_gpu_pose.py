@@ -146,12 +146,14 @@ def test_pairs_run_matches_oracle(ctx, oracle, kitti02, kitti09, K02):
         assert [r["n_kp1"], r["n_kp2"], r["n_match"], r["n_inlier"]] == counts.tolist()
         assert rot_angle(T[:3, :3], r["T"][:3, :3]) < 1e-6 and dir_angle(T[:3, 3], r["T"][:3, 3]) < 1e-6
         assert np.array_equal(r["T"][3], [0, 0, 0, 1])
-    # match indices are bit exact too (host-image path stages chunk_pairs=2 at a time: pair 2 is index 0 of the last batch)
-    k1, f1 = oracle.orb_detect_compute(A[2]); k2, f2 = oracle.orb_detect_compute(B[2])
-    i1, d1, i2, d2 = oracle.match_knn2(f1, f2)
-    keep = oracle.ratio_filter(d1, d2, 0.45)
-    mq = ctx.debug_read(L.VO_DBG_MATCHES, 0, 0, np.int32).reshape(-1, 4)
-    assert np.array_equal(mq[:, 0], keep) and np.array_equal(mq[:, 1], i1[keep])
+    # match indices are bit exact too: the context (chunk_pairs 2, max_pairs 4) has two lanes, so the host-image path stages
+    # all three pairs at once and they are rows 0..2 of the last pose wave, written by two different lanes
+    for i in range(3):
+        k1, f1 = oracle.orb_detect_compute(A[i]); k2, f2 = oracle.orb_detect_compute(B[i])
+        i1, d1, i2, d2 = oracle.match_knn2(f1, f2)
+        keep = oracle.ratio_filter(d1, d2, 0.45)
+        mq = ctx.debug_read(L.VO_DBG_MATCHES, i, 0, np.int32).reshape(-1, 4)
+        assert np.array_equal(mq[:, 0], keep) and np.array_equal(mq[:, 1], i1[keep])
 
 
 def test_pairs_run_reports_failures_per_pair(ctx, kitti02, K02):

@@ -3,6 +3,7 @@
 // /root/reference/libs/vo_utils.py).  No CPU fallback: every entry point runs HIP kernels.
 #include <algorithm>
 #include <cstring>
+#include <functional>
 
 #include "../../include/vo_orb_pattern_31.h"
 #include "vo_internal.h"
@@ -102,21 +103,24 @@ void vo_default_orb_params(vo_orb_params* p) {
     p->trig_mode = 0;
 }
 
-static int ctx_init(vo_ctx* c) {
+// Streams, events and the per-chunk workspace of ONE lane (the context itself is lane 0; extra lanes are shallow clones
+// that own only these and alias everything else).  A chunk of 2*chunk_pairs frames goes through detect + match on one
+// lane; consecutive chunks go to different lanes, so that the latency-bound kernels of one chunk (retainBest replay,
+// small pyramid levels, scans) overlap the throughput-bound kernels of the others without any help from the caller.
+static int lane_init(vo_ctx* c, bool with_aux) {
     const vo_orb_params& p = c->params;
-    HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    HIP_TRY(c, hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
+    // the blur fork (vo_launch_detect) is only used by contexts of at most two lanes: HIP multiplexes streams onto a few
+    // hardware queues, and streams that are never used would still take their turn in that assignment
+    if (with_aux) HIP_TRY(c, hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
     HIP_TRY(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
     HIP_TRY(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
-    HIP_TRY(c, hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming));
+    for (int i = 0; i < 2; i++) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_lane[i], hipEventDisableTiming));
     c->kp_cap = p.nfeatures + 1024;
-    const long F = c->max_frames, kc = c->kp_cap, MP = c->max_pairs, CP = c->chunk_pairs;
-    // geometry-sized buffers: size them for the largest image with a dry geometry pass
-    ALLOC(c, c->d_geom, sizeof(Geom));
+    const long F = c->max_frames, kc = c->kp_cap, CP = c->chunk_pairs;
     // upper bounds from the max image size (all quantities are monotone in w, h)
     const long W = c->max_w, H = c->max_h;
-    long pyr = 0, blur = 0, cand = 0, tiles = 0, segs = 0, btiles = 0, rt = 0;
+    long pyr = 0, blur = 0, cand = 0, tiles = 0, segs = 0;
     {
         const double sf = (double)p.scale_factor;
         for (int l = 0; l < p.nlevels; l++) {
@@ -130,14 +134,8 @@ static int ctx_init(vo_ctx* c) {
             tiles += ntx * nty;
             segs += (ih * ntx + 15) / 16 * 16;
             cand += (((iw + 1) / 2) * ((ih + 1) / 2) + 63) / 64 * 64;
-            btiles += ((w + 63) / 64) * ((h + 15) / 16);
-            rt += w + h + 8;
         }
     }
-    ALLOC(c, c->d_tiles, (tiles + 1) * sizeof(TileDesc));
-    ALLOC(c, c->d_btiles, (btiles + 1) * sizeof(TileDesc));
-    ALLOC(c, c->d_rtab, (rt + 1) * sizeof(ResizeCoef));
-    ALLOC(c, c->d_img, (size_t)F * W * H);
     ALLOC(c, c->d_pyr, (size_t)F * (pyr + 256));
     ALLOC(c, c->d_blur, (size_t)F * (blur + 256));
     ALLOC(c, c->d_tile_list, (size_t)F * tiles * VO_TILE_CAP * 4);
@@ -157,12 +155,66 @@ static int ctx_init(vo_ctx* c) {
     ALLOC(c, c->d_desc, (size_t)F * kc * 32);
     ALLOC(c, c->d_match, (size_t)CP * vo_match_segments(kc) * kc * sizeof(uint2));
     ALLOC(c, c->d_raw, (size_t)kc * sizeof(int4));
-    ALLOC(c, c->d_nmatch, (size_t)MP * 4);
-    ALLOC(c, c->d_pair_status, (size_t)MP * 4);
-    ALLOC(c, c->d_pair_nkp, (size_t)MP * 8);
-    ALLOC(c, c->d_mq, (size_t)MP * kc * sizeof(int4));
-    ALLOC(c, c->d_q1, (size_t)MP * kc * sizeof(float2));
-    ALLOC(c, c->d_q2, (size_t)MP * kc * sizeof(float2));
+    HIP_TRY(c, hipMemset(c->d_frame_status.p, 0, c->d_frame_status.bytes));
+    HIP_TRY(c, hipMemset(c->d_kp.p, 0, c->d_kp.bytes));
+    return VO_OK;
+}
+
+static void lane_free(vo_ctx* c) {
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->aux_stream) (void)hipStreamSynchronize(c->aux_stream);
+    DevBuf* bufs[] = {&c->d_pyr, &c->d_blur, &c->d_tile_list, &c->d_seg_cnt, &c->d_seg_ofs, &c->d_key, &c->d_payload, &c->d_lpos, &c->d_rpos,
+                      &c->d_cnt_fast, &c->d_cnt_sel1, &c->d_cnt_sel2, &c->d_nkp, &c->d_kp, &c->d_kplvl, &c->d_desc, &c->d_frame_status, &c->d_match, &c->d_raw};
+    for (DevBuf* b : bufs) dev_free(*b);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    for (int i = 0; i < 2; i++) if (c->ev_lane[i]) (void)hipEventDestroy(c->ev_lane[i]);
+    if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->counted) g_live[c->device]--;
+}
+
+// buffers of the context that every lane aliases (geometry tables, the pair arrays, the pose stage's workspace)
+static void lane_alias_shared(vo_ctx* l, const vo_ctx* c) {
+    l->d_geom = c->d_geom; l->d_tiles = c->d_tiles; l->d_btiles = c->d_btiles; l->d_rtab = c->d_rtab; l->d_pat = c->d_pat;
+    l->d_nmatch = c->d_nmatch; l->d_pair_status = c->d_pair_status; l->d_pair_nkp = c->d_pair_nkp;
+    l->d_mq = c->d_mq; l->d_q1 = c->d_q1; l->d_q2 = c->d_q2;
+}
+
+static int ctx_init(vo_ctx* c) {
+    const vo_orb_params& p = c->params;
+    HIP_TRY(c, hipSetDevice(c->device));
+    // extra lanes: one per chunk a pose wave holds, at most VO_MAX_LANES in all (a single-pair context has none)
+    int nl = (int)std::min<long>(VO_MAX_LANES, ((long)c->max_pairs + c->chunk_pairs - 1) / c->chunk_pairs);
+    if (const char* e = getenv("VO_LANES")) nl = std::max(1, std::min(8, atoi(e)));   // experiments
+    int rc = lane_init(c, nl <= 2);
+    if (rc != VO_OK) return rc;
+    HIP_TRY(c, hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming));
+    HIP_TRY(c, hipStreamCreateWithFlags(&c->pose_stream, hipStreamNonBlocking));
+    const long kc = c->kp_cap, MP = c->max_pairs;
+    const long W = c->max_w, H = c->max_h;
+    long tiles = 0, btiles = 0, rt = 0;
+    {
+        const double sf = (double)p.scale_factor;
+        for (int l = 0; l < p.nlevels; l++) {
+            const float sc = (float)std::pow(sf, (double)l);
+            const long w = (long)nearbyintf(W * (1.f / sc)) + 1, h = (long)nearbyintf(H * (1.f / sc)) + 1;
+            const long iw = std::max(w - 62, 0L), ih = std::max(h - 62, 0L);
+            tiles += ((iw + VO_TILE_W - 1) / VO_TILE_W) * ((ih + VO_TILE_H - 1) / VO_TILE_H);
+            btiles += ((w + 63) / 64) * ((h + 15) / 16);
+            rt += w + h + 8;
+        }
+    }
+    ALLOC(c, c->d_geom, sizeof(Geom));
+    ALLOC(c, c->d_tiles, (tiles + 1) * sizeof(TileDesc));
+    ALLOC(c, c->d_btiles, (btiles + 1) * sizeof(TileDesc));
+    ALLOC(c, c->d_rtab, (rt + 1) * sizeof(ResizeCoef));
+    ALLOC(c, c->d_nmatch, 2 * (size_t)MP * 4);
+    ALLOC(c, c->d_pair_status, 2 * (size_t)MP * 4);
+    ALLOC(c, c->d_pair_nkp, 2 * (size_t)MP * 8);
+    ALLOC(c, c->d_mq, 2 * (size_t)MP * kc * sizeof(int4));
+    ALLOC(c, c->d_q1, 2 * (size_t)MP * kc * sizeof(float2));
+    ALLOC(c, c->d_q2, 2 * (size_t)MP * kc * sizeof(float2));
     ALLOC(c, c->d_mask, (size_t)MP * kc);
     ALLOC(c, c->d_pose, (size_t)MP * sizeof(PoseWork));
     ALLOC(c, c->d_hyp, (size_t)MP * VO_HYP_ROUND * 90 * sizeof(double));
@@ -174,9 +226,19 @@ static int ctx_init(vo_ctx* c) {
     ALLOC(c, c->d_misc, 4096);
     ALLOC(c, c->d_pat, 1024);
     HIP_TRY(c, hipMemcpy(c->d_pat.p, VO_ORB_PATTERN_31, 1024, hipMemcpyHostToDevice));
-    HIP_TRY(c, hipMemset(c->d_frame_status.p, 0, c->d_frame_status.bytes));
     HIP_TRY(c, hipMemset(c->d_pair_status.p, 0, c->d_pair_status.bytes));
-    HIP_TRY(c, hipMemset(c->d_kp.p, 0, c->d_kp.bytes));
+    for (int i = 1; i < nl; i++) {
+        vo_ctx* l = new vo_ctx();
+        c->lanes.push_back(l);
+        l->owner = c; l->device = c->device; l->params = c->params;
+        l->max_w = c->max_w; l->max_h = c->max_h; l->chunk_pairs = c->chunk_pairs; l->max_pairs = c->max_pairs; l->max_frames = c->max_frames;
+        if (c->device < 64) { g_live[c->device]++; l->counted = true; }
+        rc = lane_init(l, nl <= 2);
+        if (rc != VO_OK) return vo_fail(c, rc, l->err);
+        lane_alias_shared(l, c);
+    }
+    // staging for the host-image entry points: one chunk per lane
+    ALLOC(c, c->d_img, (size_t)c->max_frames * nl * W * H);
     c->err.reserve(256);       // error messages after this point do not touch the heap
     return vo_noalloc_init(c);
 }
@@ -208,21 +270,17 @@ int vo_ctx_create(int device, int max_w, int max_h, int chunk_pairs, int max_pai
 
 void vo_ctx_destroy(vo_ctx* c) {
     if (!c) return;
-    if (c->counted) g_live[c->device]--;
     (void)hipSetDevice(c->device);
-    if (c->stream) { (void)hipStreamSynchronize(c->stream); }
-    DevBuf* bufs[] = {&c->d_geom, &c->d_tiles, &c->d_btiles, &c->d_rtab, &c->d_img, &c->d_pyr, &c->d_blur, &c->d_tile_list, &c->d_seg_cnt,
-                      &c->d_seg_ofs, &c->d_key, &c->d_payload, &c->d_lpos, &c->d_rpos, &c->d_cnt_fast, &c->d_cnt_sel1, &c->d_cnt_sel2, &c->d_nkp,
-                      &c->d_kp, &c->d_kplvl, &c->d_desc, &c->d_frame_status, &c->d_match, &c->d_nmatch, &c->d_mq, &c->d_q1, &c->d_q2, &c->d_pose,
+    if (c->pose_stream) (void)hipStreamSynchronize(c->pose_stream);
+    for (vo_ctx* l : c->lanes) { lane_free(l); delete l; }
+    lane_free(c);
+    DevBuf* bufs[] = {&c->d_geom, &c->d_tiles, &c->d_btiles, &c->d_rtab, &c->d_img, &c->d_nmatch, &c->d_mq, &c->d_q1, &c->d_q2, &c->d_pose,
                       &c->d_hyp, &c->d_mask, &c->d_result, &c->d_misc, &c->d_pat, &c->d_pair_status, &c->d_samples, &c->d_nmodels, &c->d_counts,
-                      &c->d_vote, &c->d_pair_nkp, &c->d_raw, &c->d_tri};
+                      &c->d_vote, &c->d_pair_nkp, &c->d_tri};
     for (DevBuf* b : bufs) dev_free(*b);
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
-    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
-    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->ev_in) (void)hipEventDestroy(c->ev_in);
-    if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
-    if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->pose_stream) (void)hipStreamDestroy(c->pose_stream);
     delete c;
 }
 
@@ -231,6 +289,7 @@ const char* vo_last_error(const vo_ctx* c) { return c ? c->err.c_str() : "null c
 int vo_set_debug_stop(vo_ctx* c, int stage) {
     if (!c || stage < 0 || stage > 2) return VO_ERR_INVALID;
     c->debug_stop = stage;
+    for (vo_ctx* l : c->lanes) l->debug_stop = stage;
     return VO_OK;
 }
 
@@ -248,6 +307,13 @@ int vo_get_kernel_timing(vo_ctx* c, float ms[VO_N_KERNELS], int32_t launches[VO_
 }
 
 // -------------------------------------------------------------------- detectAndCompute
+// host frames -> tight device frames.  Contiguous rows (stride == w, the usual case) go as ONE linear copy: hipMemcpy2D from
+// pageable memory copies row by row (measured 0.13 GB/s for 1241-byte rows against ~20 GB/s for the linear copy).
+static hipError_t copy_frames_h2d(void* dst, const uint8_t* src, int w, int stride, size_t rows) {
+    if (stride == w) return hipMemcpy(dst, src, (size_t)w * rows, hipMemcpyHostToDevice);
+    return hipMemcpy2D(dst, w, src, stride, w, rows, hipMemcpyHostToDevice);
+}
+
 int vo_orb_detect_compute(vo_ctx* c, const uint8_t* img, int w, int h, int stride, vo_keypoint* kps, uint8_t* desc, int cap, int* n) {
     if (!c) return VO_ERR_INVALID;
     if (!img || !n || w <= 0 || h <= 0 || stride < w) return vo_fail(c, VO_ERR_INVALID, "vo_orb_detect_compute: bad arguments");
@@ -255,9 +321,9 @@ int vo_orb_detect_compute(vo_ctx* c, const uint8_t* img, int w, int h, int strid
     int rc = vo_build_geometry(c, w, h);
     if (rc != VO_OK) return rc;
     hipStream_t st = c->stream;
-    HIP_TRY(c, hipMemcpy2DAsync(c->d_img.p, w, img, stride, w, h, hipMemcpyHostToDevice, st));
+    HIP_TRY(c, copy_frames_h2d(c->d_img.p, img, w, stride, (size_t)h));
     FrameSrc src{(const uint8_t*)c->d_img.p, (const uint8_t*)c->d_img.p, 1, w, (long)w * h};
-    c->last_src = src; c->last_frames = 1; c->last_pairs = 0;
+    c->last_src = src; c->last_frames = 1; c->last_pairs = 0; c->last_lane = 0;
     rc = vo_launch_detect(c, src, 1, st);
     if (rc != VO_OK) return rc;
     int hn[2] = {0, 0};
@@ -281,13 +347,14 @@ static int match_host(vo_ctx* c, const uint8_t* q, int nq, const uint8_t* t, int
     if (nt < 2) return vo_fail(c, VO_ERR_TOO_FEW, "knnMatch(k=2) needs at least 2 train descriptors");
     HIP_TRY(c, hipSetDevice(c->device));
     hipStream_t st = c->stream;
+    c->slot = 0;
     const long kc = c->kp_cap;
     int hn[2] = {nq, nt};
     HIP_TRY(c, hipMemcpyAsync(c->d_nkp.p, hn, 8, hipMemcpyHostToDevice, st));
     HIP_TRY(c, hipMemsetAsync(c->d_frame_status.p, 0, 8, st));
     if (nq) HIP_TRY(c, hipMemcpyAsync(c->d_desc.p, q, (size_t)nq * 32, hipMemcpyHostToDevice, st));
     HIP_TRY(c, hipMemcpyAsync((uint8_t*)c->d_desc.p + kc * 32, t, (size_t)nt * 32, hipMemcpyHostToDevice, st));
-    c->last_pairs = 1;
+    c->last_pairs = 1; c->last_lane = 0;
     int rc = vo_launch_match_impl(c, 1, 1, ratio, 0, want_raw ? (int4*)c->d_raw.p : nullptr, st);
     if (rc != VO_OK) return rc;
     HIP_TRY(c, hipStreamSynchronize(st));
@@ -316,11 +383,11 @@ int vo_match_knn2_ratio(vo_ctx* c, const uint8_t* q, int nq, const uint8_t* t, i
     int rc = match_host(c, q, nq, t, nt, ratio, false);
     if (rc != VO_OK) return rc;
     int nm = 0;
-    HIP_TRY(c, hipMemcpy(&nm, c->d_nmatch.p, 4, hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(&nm, c->nmatch(), 4, hipMemcpyDeviceToHost));
     *n = nm;
     if (nm > cap) return vo_fail(c, VO_ERR_CAPACITY, "vo_match_knn2_ratio: output capacity too small");
     std::vector<int4> m(std::max(nm, 1));
-    if (nm) HIP_TRY(c, hipMemcpy(m.data(), c->d_mq.p, (size_t)nm * sizeof(int4), hipMemcpyDeviceToHost));
+    if (nm) HIP_TRY(c, hipMemcpy(m.data(), c->mq(), (size_t)nm * sizeof(int4), hipMemcpyDeviceToHost));
     for (int i = 0; i < nm; i++) {
         if (qidx) qidx[i] = m[i].x;
         if (tidx) tidx[i] = m[i].y;
@@ -334,11 +401,12 @@ int vo_match_knn2_ratio(vo_ctx* c, const uint8_t* q, int nq, const uint8_t* t, i
 static int upload_points(vo_ctx* c, const float* q1, const float* q2, int n, hipStream_t st) {
     if (n > c->kp_cap) return vo_fail(c, VO_ERR_CAPACITY, "more points than the context's keypoint capacity");
     int hn = n, zero = 0;
-    HIP_TRY(c, hipMemcpyAsync(c->d_nmatch.p, &hn, 4, hipMemcpyHostToDevice, st));
-    HIP_TRY(c, hipMemcpyAsync(c->d_pair_status.p, &zero, 4, hipMemcpyHostToDevice, st));
+    c->slot = 0;
+    HIP_TRY(c, hipMemcpyAsync(c->nmatch(), &hn, 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(c, hipMemcpyAsync(c->pair_status(), &zero, 4, hipMemcpyHostToDevice, st));
     if (n) {
-        HIP_TRY(c, hipMemcpyAsync(c->d_q1.p, q1, (size_t)n * 8, hipMemcpyHostToDevice, st));
-        HIP_TRY(c, hipMemcpyAsync(c->d_q2.p, q2, (size_t)n * 8, hipMemcpyHostToDevice, st));
+        HIP_TRY(c, hipMemcpyAsync(c->q1(), q1, (size_t)n * 8, hipMemcpyHostToDevice, st));
+        HIP_TRY(c, hipMemcpyAsync(c->q2(), q2, (size_t)n * 8, hipMemcpyHostToDevice, st));
     }
     HIP_TRY(c, hipStreamSynchronize(st));  // the host scalars above are stack variables
     return VO_OK;
@@ -419,8 +487,9 @@ int vo_triangulate(vo_ctx* c, const double P1[12], const double P2[12], const fl
 
 // -------------------------------------------------------------------- batched pairs
 // pose stage (findEssentialMat + recoverPose) over the Pb pairs matched so far, results to host
-static int pose_stage(vo_ctx* c, int Pb, const double K[9], vo_pair_result* out, hipStream_t st) {
+static int pose_stage(vo_ctx* c, int Pb, const double K[9], vo_pair_result* out, hipStream_t st, const std::vector<hipEvent_t>& after = {}) {
     c->last_pairs = Pb;
+    for (hipEvent_t e : after) HIP_TRY(c, hipStreamWaitEvent(st, e, 0));
     kt_begin(c, st, VO_K_RANSAC);
     int rc = vo_launch_ransac(c, Pb, K, 0.999, 1.0, 1000, st);
     kt_end(c, st);
@@ -429,21 +498,98 @@ static int pose_stage(vo_ctx* c, int Pb, const double K[9], vo_pair_result* out,
     rc = vo_launch_recover(c, Pb, K, 50.0, st);
     kt_end(c, st);
     if (rc != VO_OK) return rc;
-    hipLaunchKernelGGL(k_results, dim3((Pb + 63) / 64), dim3(64), 0, st, (const PoseWork*)c->d_pose.p, (const int*)c->d_nmatch.p,
-                       (const int2*)c->d_pair_nkp.p, Pb, (vo_pair_result*)c->d_result.p);
+    hipLaunchKernelGGL(k_results, dim3((Pb + 63) / 64), dim3(64), 0, st, (const PoseWork*)c->d_pose.p, (const int*)c->nmatch(),
+                       (const int2*)c->pair_nkp(), Pb, (vo_pair_result*)c->d_result.p);
     HIP_TRY(c, hipMemcpyAsync(out, c->d_result.p, (size_t)Pb * sizeof(vo_pair_result), hipMemcpyDeviceToHost, st));
     HIP_TRY(c, hipStreamSynchronize(st));
     if (c->timing) kt_collect(c);
     return VO_OK;
 }
 
-// Stream-ordering contract of the *_device entry points: with an explicit stream the work is enqueued on it, in order
-// with whatever the caller put there before.  With stream == NULL the work runs on the context's private (non-blocking)
-// stream, which is first made to wait for everything enqueued so far on the device's default stream -- the stream a
-// framework's tensor ops (torch's default stream) produce the images on -- so un-synchronised producers are safe.
-static int order_after_default(vo_ctx* c) {
-    HIP_TRY(c, hipEventRecord(c->ev_in, nullptr));
-    HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_in, 0));
+// Stream-ordering contract of the *_device entry points: the work is ordered after everything the caller has enqueued on
+// `stream` (hipStream_t), or, with stream == NULL, on the device's default stream -- the stream a framework's tensor ops
+// (torch's default stream) produce the images on -- so un-synchronised producers are safe.  The kernels themselves run on
+// the context's private streams (one per lane + the pose stream); the call returns after the results are in `out`.
+static int order_after(vo_ctx* c, hipStream_t producer, const std::vector<hipStream_t>& consumers) {
+    HIP_TRY(c, hipEventRecord(c->ev_in, producer));
+    for (hipStream_t s : consumers)
+        if (s != producer) HIP_TRY(c, hipStreamWaitEvent(s, c->ev_in, 0));
+    return VO_OK;
+}
+
+static int propagate_geometry(vo_ctx* c) {
+    for (vo_ctx* l : c->lanes) { l->geom = c->geom; l->geom_valid = c->geom_valid; }
+    return VO_OK;
+}
+
+// B pairs in pose waves ("batches") of max_pairs pairs, each made of chunks of `cp` pairs.  chunk(L, st, b0, p0, Pc)
+// enqueues detect + match of pairs [b0 + p0, b0 + p0 + Pc) on lane L / stream st, writing rows p0.. of the pair arrays.
+// Consecutive chunks go to different lanes (round-robin), all enqueued by this one host thread without a
+// synchronisation.  The pose stage of batch b runs on the pose stream after the lanes' events, and its host-synchronised
+// RANSAC rounds are issued only after detect + match of batch b+1 have been enqueued, so they overlap them; the pair
+// arrays the two stages share exist twice (vo_ctx::slot).  In the timing mode everything runs on ONE stream, one
+// kernel at a time (HIP events bracket every launch).
+static int run_batches(vo_ctx* c, int B, int cp, const double K[9], vo_pair_result* out, hipStream_t user,
+                       const std::function<int(vo_ctx*, hipStream_t, int, int, int)>& chunk) {
+    const bool serial = c->timing;
+    const int nl = serial ? 1 : 1 + (int)c->lanes.size();
+    auto lane = [&](int i) { return i == 0 ? c : c->lanes[i - 1]; };
+    std::vector<hipStream_t> lst(nl);
+    for (int i = 0; i < nl; i++) lst[i] = lane(i)->stream;
+    if (serial && user) lst[0] = user;
+    hipStream_t pst = serial ? lst[0] : c->pose_stream;
+    int rc = order_after(c, user, lst);
+    if (rc != VO_OK) return rc;
+    auto drain = [&](int r) {
+        for (hipStream_t s : lst) (void)hipStreamSynchronize(s);
+        (void)hipStreamSynchronize(pst);
+        return r;
+    };
+    struct Pending { int b0 = -1, Pb = 0, slot = 0; std::vector<hipEvent_t> ev; } pend;
+    int nb = 0, nchunk = 0;
+    for (int b0 = 0; b0 < B; b0 += c->max_pairs, nb++) {
+        const int Pb = std::min(c->max_pairs, B - b0);
+        const int slot = nb & 1;
+        c->slot = slot;
+        unsigned used = 0;
+        for (int p0 = 0; p0 < Pb; p0 += cp, nchunk++) {
+            const int li = nchunk % nl;
+            vo_ctx* L = lane(li);
+            L->slot = slot;
+            rc = chunk(L, lst[li], b0, p0, std::min(cp, Pb - p0));
+            if (rc != VO_OK) return drain(L != c ? vo_fail(c, rc, L->err) : rc);
+            c->last_lane = li;
+            used |= 1u << li;
+            if (serial) {
+                if (hipStreamSynchronize(lst[0]) != hipSuccess) return vo_fail(c, VO_ERR_HIP, "hipStreamSynchronize failed");
+                kt_collect(c);
+            }
+        }
+        if (serial) {
+            rc = pose_stage(c, Pb, K, out + b0, pst);
+            if (rc != VO_OK) return drain(rc);
+            continue;
+        }
+        Pending cur;
+        cur.b0 = b0; cur.Pb = Pb; cur.slot = slot;
+        for (int li = 0; li < nl; li++)
+            if (used >> li & 1) {
+                if (hipEventRecord(lane(li)->ev_lane[slot], lst[li]) != hipSuccess) return drain(vo_fail(c, VO_ERR_HIP, "hipEventRecord failed"));
+                cur.ev.push_back(lane(li)->ev_lane[slot]);
+            }
+        if (pend.b0 >= 0) {
+            c->slot = pend.slot;
+            rc = pose_stage(c, pend.Pb, K, out + pend.b0, pst, pend.ev);
+            c->slot = slot;
+            if (rc != VO_OK) return drain(rc);
+        }
+        pend = cur;
+    }
+    if (pend.b0 >= 0) {
+        c->slot = pend.slot;
+        rc = pose_stage(c, pend.Pb, K, out + pend.b0, pst, pend.ev);
+        if (rc != VO_OK) return drain(rc);
+    }
     return VO_OK;
 }
 
@@ -455,28 +601,15 @@ int vo_pairs_run_device(vo_ctx* c, const uint8_t* imgsA, const uint8_t* imgsB, i
     HIP_TRY(c, hipSetDevice(c->device));
     int rc = vo_build_geometry(c, w, h);
     if (rc != VO_OK) return rc;
-    hipStream_t st = stream ? (hipStream_t)stream : c->stream;
-    if (!stream) { int rc2 = order_after_default(c); if (rc2 != VO_OK) return rc2; }
+    propagate_geometry(c);
     const long fs = (long)stride * h;
-    for (int b0 = 0; b0 < B; b0 += c->max_pairs) {
-        const int Pb = std::min(c->max_pairs, B - b0);
-        for (int p0 = 0; p0 < Pb; p0 += c->chunk_pairs) {
-            const int Pc = std::min(c->chunk_pairs, Pb - p0);
-            FrameSrc src{imgsA + (long)(b0 + p0) * fs, imgsB + (long)(b0 + p0) * fs, Pc, stride, fs};
-            c->last_src = src; c->last_frames = 2 * Pc;
-            rc = vo_launch_detect(c, src, 2 * Pc, st);
-            if (rc != VO_OK) return rc;
-            rc = vo_launch_match_impl(c, Pc, Pc, ratio, p0, nullptr, st);
-            if (rc != VO_OK) return rc;
-            if (c->timing) {
-                HIP_TRY(c, hipStreamSynchronize(st));
-                kt_collect(c);
-            }
-        }
-        rc = pose_stage(c, Pb, K, out + b0, st);
-        if (rc != VO_OK) return rc;
-    }
-    return VO_OK;
+    return run_batches(c, B, c->chunk_pairs, K, out, (hipStream_t)stream, [&](vo_ctx* L, hipStream_t st, int b0, int p0, int Pc) {
+        FrameSrc src{imgsA + (long)(b0 + p0) * fs, imgsB + (long)(b0 + p0) * fs, Pc, stride, fs};
+        L->last_src = src; L->last_frames = 2 * Pc;
+        int r = vo_launch_detect(L, src, 2 * Pc, st);
+        if (r != VO_OK) return r;
+        return vo_launch_match_impl(L, Pc, Pc, ratio, p0, nullptr, st);
+    });
 }
 
 // A sequence of F frames: pair i is (frame i, frame i+1), as the loop of vo.py:48-190 visits them.
@@ -490,32 +623,18 @@ int vo_sequence_run_device(vo_ctx* c, const uint8_t* imgs, int F, int w, int h, 
     HIP_TRY(c, hipSetDevice(c->device));
     int rc = vo_build_geometry(c, w, h);
     if (rc != VO_OK) return rc;
-    hipStream_t st = stream ? (hipStream_t)stream : c->stream;
-    if (!stream) { int rc2 = order_after_default(c); if (rc2 != VO_OK) return rc2; }
+    propagate_geometry(c);
     const long fs = (long)stride * h;
-    const int B = F - 1;
     // a chunk of Pc pairs needs Pc+1 frames of the 2*chunk_pairs-frame workspace and Pc rows of the match workspace
     const int cp = std::min(c->chunk_pairs, 2 * c->chunk_pairs - 1);
-    for (int b0 = 0; b0 < B; b0 += c->max_pairs) {
-        const int Pb = std::min(c->max_pairs, B - b0);
-        for (int p0 = 0; p0 < Pb; p0 += cp) {
-            const int Pc = std::min(cp, Pb - p0);
-            const uint8_t* first = imgs + (long)(b0 + p0) * fs;
-            FrameSrc src{first, first, Pc + 1, stride, fs};
-            c->last_src = src; c->last_frames = Pc + 1;
-            rc = vo_launch_detect(c, src, Pc + 1, st);
-            if (rc != VO_OK) return rc;
-            rc = vo_launch_match_impl(c, Pc, 1, ratio, p0, nullptr, st);   // train frame of pair p = frame p + 1
-            if (rc != VO_OK) return rc;
-            if (c->timing) {
-                HIP_TRY(c, hipStreamSynchronize(st));
-                kt_collect(c);
-            }
-        }
-        rc = pose_stage(c, Pb, K, out + b0, st);
-        if (rc != VO_OK) return rc;
-    }
-    return VO_OK;
+    return run_batches(c, F - 1, cp, K, out, (hipStream_t)stream, [&](vo_ctx* L, hipStream_t st, int b0, int p0, int Pc) {
+        const uint8_t* first = imgs + (long)(b0 + p0) * fs;
+        FrameSrc src{first, first, Pc + 1, stride, fs};
+        L->last_src = src; L->last_frames = Pc + 1;
+        int r = vo_launch_detect(L, src, Pc + 1, st);
+        if (r != VO_OK) return r;
+        return vo_launch_match_impl(L, Pc, 1, ratio, p0, nullptr, st);   // train frame of pair p = frame p + 1
+    });
 }
 
 int vo_sequence_run(vo_ctx* c, const uint8_t* imgs, int F, int w, int h, int stride, const double K[9], double ratio, vo_pair_result* out) {
@@ -525,11 +644,11 @@ int vo_sequence_run(vo_ctx* c, const uint8_t* imgs, int F, int w, int h, int str
     HIP_TRY(c, hipSetDevice(c->device));
     // stage through device memory: up to 2*chunk_pairs frames at a time, consecutive stages share one frame
     const long fs = (long)w * h;
-    const int cap = (int)std::min<long>(2L * c->chunk_pairs, (long)(c->d_img.bytes / fs));
+    const int cap = (int)std::min<long>(2L * c->chunk_pairs * (1 + (long)c->lanes.size()), (long)(c->d_img.bytes / fs));
     if (cap < 2) return vo_fail(c, VO_ERR_CAPACITY, "vo_sequence_run: staging buffer too small");
     for (int f0 = 0; f0 < F - 1; f0 += cap - 1) {
         const int nf = std::min(cap, F - f0);
-        HIP_TRY(c, hipMemcpy2D(c->d_img.p, w, imgs + (long)f0 * stride * h, stride, w, (size_t)h * nf, hipMemcpyHostToDevice));
+        HIP_TRY(c, copy_frames_h2d(c->d_img.p, imgs + (long)f0 * stride * h, w, stride, (size_t)h * nf));
         int rc = vo_sequence_run_device(c, (const uint8_t*)c->d_img.p, nf, w, h, w, K, ratio, out + f0, nullptr);
         if (rc != VO_OK) return rc;
     }
@@ -543,13 +662,14 @@ int vo_pairs_run(vo_ctx* c, const uint8_t* imgsA, const uint8_t* imgsB, int B, i
     HIP_TRY(c, hipSetDevice(c->device));
     // stage through device memory in super-batches of chunk_pairs pairs (d_img holds 2*chunk_pairs frames)
     const long fs = (long)w * h;
-    for (int b0 = 0; b0 < B; b0 += c->chunk_pairs) {
-        const int Pc = std::min(c->chunk_pairs, B - b0);
+    const int stage = c->chunk_pairs * (1 + (int)c->lanes.size());   // d_img holds one chunk per lane
+    for (int b0 = 0; b0 < B; b0 += stage) {
+        const int Pc = std::min(stage, B - b0);
         if ((size_t)(2 * Pc * fs) > c->d_img.bytes) return vo_fail(c, VO_ERR_CAPACITY, "vo_pairs_run: staging buffer too small");
         uint8_t* dA = (uint8_t*)c->d_img.p;
         uint8_t* dB = dA + (long)Pc * fs;
-        HIP_TRY(c, hipMemcpy2D(dA, w, imgsA + (long)b0 * stride * h, stride, w, (size_t)h * Pc, hipMemcpyHostToDevice));
-        HIP_TRY(c, hipMemcpy2D(dB, w, imgsB + (long)b0 * stride * h, stride, w, (size_t)h * Pc, hipMemcpyHostToDevice));
+        HIP_TRY(c, copy_frames_h2d(dA, imgsA + (long)b0 * stride * h, w, stride, (size_t)h * Pc));
+        HIP_TRY(c, copy_frames_h2d(dB, imgsB + (long)b0 * stride * h, w, stride, (size_t)h * Pc));
         int rc = vo_pairs_run_device(c, dA, dB, Pc, w, h, w, K, ratio, out + b0, nullptr);
         if (rc != VO_OK) return rc;
     }
@@ -562,6 +682,7 @@ long vo_debug_read(vo_ctx* c, int what, int index, int level, void* out, long by
     if (hipSetDevice(c->device) != hipSuccess) return VO_ERR_HIP;
     (void)hipDeviceSynchronize();
     const Geom& g = c->geom;
+    const vo_ctx* ln = c->last_lane == 0 ? c : c->lanes[c->last_lane - 1];   // chunk-level buffers: the lane of the last chunk
     const long kc = c->kp_cap;
     auto copy = [&](const void* src, long have) -> long {
         if (out && have > 0 && bytes > 0 && hipMemcpy(out, src, (size_t)std::min(have, bytes), hipMemcpyDeviceToHost) != hipSuccess) return VO_ERR_HIP;
@@ -575,16 +696,16 @@ long vo_debug_read(vo_ctx* c, int what, int index, int level, void* out, long by
     switch (what) {
         case VO_DBG_PYR_LEVEL:
         case VO_DBG_BLUR_LEVEL: {
-            if (index < 0 || index >= c->last_frames || level < 0 || level >= g.nlevels) return VO_ERR_INVALID;
+            if (index < 0 || index >= ln->last_frames || level < 0 || level >= g.nlevels) return VO_ERR_INVALID;
             const LevelGeom& L = g.lv[level];
             const uint8_t* src;
             long pitch;
-            if (what == VO_DBG_BLUR_LEVEL) { src = (const uint8_t*)c->d_blur.p + (long)index * g.blur_frame + L.blur_ofs; pitch = L.bpitch; }
+            if (what == VO_DBG_BLUR_LEVEL) { src = (const uint8_t*)ln->d_blur.p + (long)index * g.blur_frame + L.blur_ofs; pitch = L.bpitch; }
             else if (level == 0) {
-                const FrameSrc& s = c->last_src;
+                const FrameSrc& s = ln->last_src;
                 src = index < s.nA ? s.a + (long)index * s.frame_stride : s.b + (long)(index - s.nA) * s.frame_stride;
                 pitch = s.pitch;
-            } else { src = (const uint8_t*)c->d_pyr.p + (long)index * g.pyr_frame + L.pyr_ofs; pitch = L.pitch; }
+            } else { src = (const uint8_t*)ln->d_pyr.p + (long)index * g.pyr_frame + L.pyr_ofs; pitch = L.pitch; }
             const long have = (long)L.w * L.h;
             if (out && bytes >= have && hipMemcpy2D(out, L.w, src, pitch, L.w, L.h, hipMemcpyDeviceToHost) != hipSuccess) return VO_ERR_HIP;
             return have;
@@ -592,14 +713,14 @@ long vo_debug_read(vo_ctx* c, int what, int index, int level, void* out, long by
         case VO_DBG_FAST_LIST:
         case VO_DBG_SEL1_LIST:
         case VO_DBG_SEL1_HARRIS: {
-            if (index < 0 || index >= c->last_frames || level < 0 || level >= g.nlevels) return VO_ERR_INVALID;
-            const int n = read_int(what == VO_DBG_FAST_LIST ? c->d_cnt_fast.p : c->d_cnt_sel1.p, (long)index * VO_MAX_LEVELS + level);
+            if (index < 0 || index >= ln->last_frames || level < 0 || level >= g.nlevels) return VO_ERR_INVALID;
+            const int n = read_int(what == VO_DBG_FAST_LIST ? ln->d_cnt_fast.p : ln->d_cnt_sel1.p, (long)index * VO_MAX_LEVELS + level);
             const long off = (long)index * g.cand_frame + g.lv[level].cand_ofs;
-            if (what == VO_DBG_SEL1_HARRIS) return copy((const float*)c->d_key.p + off, (long)n * 4);
+            if (what == VO_DBG_SEL1_HARRIS) return copy((const float*)ln->d_key.p + off, (long)n * 4);
             const long have = (long)n * 12;
             if (out && bytes >= have && n > 0) {
                 std::vector<uint32_t> pk(n);
-                if (hipMemcpy(pk.data(), (const uint32_t*)c->d_payload.p + off, (size_t)n * 4, hipMemcpyDeviceToHost) != hipSuccess) return VO_ERR_HIP;
+                if (hipMemcpy(pk.data(), (const uint32_t*)ln->d_payload.p + off, (size_t)n * 4, hipMemcpyDeviceToHost) != hipSuccess) return VO_ERR_HIP;
                 int32_t* o = (int32_t*)out;
                 for (int i = 0; i < n; i++) { o[3 * i] = UNPACK_X(pk[i]); o[3 * i + 1] = UNPACK_Y(pk[i]); o[3 * i + 2] = UNPACK_S(pk[i]); }
             }
@@ -607,19 +728,19 @@ long vo_debug_read(vo_ctx* c, int what, int index, int level, void* out, long by
         }
         case VO_DBG_KEYPOINTS:
         case VO_DBG_DESCRIPTORS: {
-            if (index < 0 || index >= c->last_frames) return VO_ERR_INVALID;
-            const int n = read_int(c->d_nkp.p, index);
-            if (what == VO_DBG_KEYPOINTS) return copy((const vo_keypoint*)c->d_kp.p + (long)index * kc, (long)n * sizeof(vo_keypoint));
-            return copy((const uint8_t*)c->d_desc.p + (long)index * kc * 32, (long)n * 32);
+            if (index < 0 || index >= ln->last_frames) return VO_ERR_INVALID;
+            const int n = read_int(ln->d_nkp.p, index);
+            if (what == VO_DBG_KEYPOINTS) return copy((const vo_keypoint*)ln->d_kp.p + (long)index * kc, (long)n * sizeof(vo_keypoint));
+            return copy((const uint8_t*)ln->d_desc.p + (long)index * kc * 32, (long)n * 32);
         }
         case VO_DBG_MATCHES: {
             if (index < 0 || index >= c->last_pairs) return VO_ERR_INVALID;
-            const int n = read_int(c->d_nmatch.p, index);
-            return copy((const int4*)c->d_mq.p + (long)index * kc, (long)n * 16);
+            const int n = read_int(c->nmatch(), index);
+            return copy((const int4*)c->mq() + (long)index * kc, (long)n * 16);
         }
         case VO_DBG_E_MASK: {
             if (index < 0 || index >= c->last_pairs) return VO_ERR_INVALID;
-            const int n = read_int(c->d_nmatch.p, index);
+            const int n = read_int(c->nmatch(), index);
             const long have = 72 + n;
             if (out && bytes >= have) {
                 PoseWork w;

@@ -14,6 +14,7 @@
 #define VO_TILE_CAP 512     // a 60x30 tile holds at most 30*15 = 450 strict 3x3 maxima
 #define VO_BLUR_TW 64
 #define VO_BLUR_TH 64
+#define VO_MAX_LANES 4      // chunk workspaces (+ streams) per context, used round-robin
 
 struct LevelGeom {
     int w, h, pitch;        // level size; row pitch of the level inside the pyramid slab
@@ -121,6 +122,22 @@ struct vo_ctx {
     DevBuf d_pair_status;  // int [max_pairs]
     DevBuf d_samples, d_nmodels, d_counts, d_vote, d_pair_nkp, d_raw, d_tri;
     int kp_cap = 0;
+    // The arrays the match stage hands to the pose stage exist twice ("slots"): while the pose stage of one batch of pairs
+    // runs on pose_stream, detect + match of the next batch fill the other slot on the main stream.
+    int slot = 0;
+    int* nmatch() const { return (int*)d_nmatch.p + (size_t)slot * max_pairs; }
+    int* pair_status() const { return (int*)d_pair_status.p + (size_t)slot * max_pairs; }
+    int2* pair_nkp() const { return (int2*)d_pair_nkp.p + (size_t)slot * max_pairs; }
+    int4* mq() const { return (int4*)d_mq.p + (size_t)slot * max_pairs * kp_cap; }
+    float2* q1() const { return (float2*)d_q1.p + (size_t)slot * max_pairs * kp_cap; }
+    float2* q2() const { return (float2*)d_q2.p + (size_t)slot * max_pairs * kp_cap; }
+    hipStream_t pose_stream = nullptr;
+    // Lanes: the context is lane 0; `lanes` are shallow clones owning a chunk workspace + streams of their own and
+    // aliasing the geometry tables and pair arrays of `owner` (vo_api.hip: lane_init / lane_alias_shared).
+    vo_ctx* owner = nullptr;
+    std::vector<vo_ctx*> lanes;
+    int last_lane = 0;                              // lane of the last chunk (vo_debug_read)
+    hipEvent_t ev_lane[2] = {nullptr, nullptr};     // this lane's chunks of the batch in slot s have been enqueued
     int debug_stop = 0;    // 0: run everything; 1: stop after FAST emit; 2: stop after retainBest #1 + Harris
     void* h_pinned = nullptr;
     size_t h_pinned_bytes = 0;

@@ -259,8 +259,8 @@ int vo_launch_match_impl(vo_ctx* c, int P, int nA, double ratio, int pair0, int4
     KT(c, st, VO_K_MATCH, hipLaunchKernelGGL(k_match<3>, dim3((kp_cap + 383) / 384, nseg, P), dim3(256), 0, st, (const uint8_t*)c->d_desc.p,
                                              (const int*)c->d_nkp.p, kp_cap, nA, nseg, (uint2*)c->d_match.p));
     KT(c, st, VO_K_RATIO, hipLaunchKernelGGL(k_ratio, dim3(P), dim3(1024), 0, st, (const uint2*)c->d_match.p, nseg, (const int*)c->d_nkp.p, kp_cap, nA,
-                       (const vo_keypoint*)c->d_kp.p, ratio, pair0, (int4*)c->d_mq.p, (float2*)c->d_q1.p, (float2*)c->d_q2.p,
-                       (int*)c->d_nmatch.p, (int*)c->d_pair_status.p, (int2*)c->d_pair_nkp.p, (const int*)c->d_frame_status.p, raw_out));
+                       (const vo_keypoint*)c->d_kp.p, ratio, pair0, (int4*)c->mq(), (float2*)c->q1(), (float2*)c->q2(),
+                       (int*)c->nmatch(), (int*)c->pair_status(), (int2*)c->pair_nkp(), (const int*)c->d_frame_status.p, raw_out));
     HIP_TRY(c, hipGetLastError());
     return VO_OK;
 }

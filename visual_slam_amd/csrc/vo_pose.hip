@@ -767,16 +767,16 @@ int vo_launch_ransac(vo_ctx* c, int P, const double K[9], double prob, double th
     const double threshold = thr / ((K[0] + K[4]) / 2);
     const float thr2 = (float)(threshold * threshold);
     PoseWork* pw = (PoseWork*)c->d_pose.p;
-    const int* nmatch = (const int*)c->d_nmatch.p;
-    const float2* q1 = (const float2*)c->d_q1.p;
-    const float2* q2 = (const float2*)c->d_q2.p;
+    const int* nmatch = (const int*)c->nmatch();
+    const float2* q1 = (const float2*)c->q1();
+    const float2* q2 = (const float2*)c->q2();
     int* samples = (int*)c->d_samples.p;
     double* models = (double*)c->d_hyp.p;
     int* nmodels = (int*)c->d_nmodels.p;
     int* counts = (int*)c->d_counts.p;
     int* active = (int*)c->d_misc.p;
     const int pb = (P + 63) / 64;
-    hipLaunchKernelGGL(k_ransac_init, dim3(pb), dim3(64), 0, st, pw, nmatch, (const int*)c->d_pair_status.p, P, max_iters);
+    hipLaunchKernelGGL(k_ransac_init, dim3(pb), dim3(64), 0, st, pw, nmatch, (const int*)c->pair_status(), P, max_iters);
     // The first round is small: with the usual inlier ratios the adaptive iteration count drops below it
     // after the first good model, and a small round packs several pairs into one solver wavefront.
     const int first_round = 16;   // a power of two <= VO_HYP_ROUND (k_ransac_solve packs DK_T / nh pairs per wavefront)
@@ -807,8 +807,8 @@ int vo_launch_recover(vo_ctx* c, int P, const double K[9], double dist_thresh, h
     int* vote = (int*)c->d_vote.p;
     const int pb = (P + 63) / 64;
     hipLaunchKernelGGL(k_decompose, dim3(pb), dim3(64), 0, st, pw, P, vote);
-    hipLaunchKernelGGL(k_cheirality, dim3((kp_cap + 63) / 64, P, 4), dim3(64), 0, st, pw, (const int*)c->d_nmatch.p, kp_cap,
-                       (const float2*)c->d_q1.p, (const float2*)c->d_q2.p, nk, dist_thresh, vote);
+    hipLaunchKernelGGL(k_cheirality, dim3((kp_cap + 63) / 64, P, 4), dim3(64), 0, st, pw, (const int*)c->nmatch(), kp_cap,
+                       (const float2*)c->q1(), (const float2*)c->q2(), nk, dist_thresh, vote);
     hipLaunchKernelGGL(k_pose_pick, dim3(pb), dim3(64), 0, st, pw, P, vote);
     HIP_TRY(c, hipGetLastError());
     return VO_OK;
