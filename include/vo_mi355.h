@@ -124,6 +124,13 @@ int vo_recover_pose(vo_ctx* ctx, const double E[9], const float* q1, const float
 int vo_triangulate(vo_ctx* ctx, const double P1[12], const double P2[12], const float* x1, const float* x2,
                    int n, float* X4);
 
+/* Replaces the whole of get_matches (libs/vo_utils.py:83-110: imread'ed frames -> detectAndCompute x2 -> knnMatch ->
+ * ratio loop -> q1, q2) in one call: imgA = previous frame, imgB = current frame, host, 8-bit gray.  q1,q2: host
+ * float32 [cap][2], the matched pixel positions in ascending queryIdx; *n their number.  Fewer than 2 keypoints in
+ * the current frame -> VO_ERR_TOO_FEW (the reference's `for m,n in matches` raises there). */
+int vo_get_matches(vo_ctx* ctx, const uint8_t* imgA, const uint8_t* imgB, int w, int h, int stride, double ratio,
+                   float* q1, float* q2, int cap, int* n);
+
 /* The whole per-pair path for a batch of B independent frame pairs whose images are
  * already resident in device memory: imgsA/imgsB are dev pointers to [B][h][stride]
  * uint8 (previous / current frames).  out: HOST array [B].  Detect+match run in chunks of
@@ -143,6 +150,18 @@ int vo_pairs_run(vo_ctx* ctx, const uint8_t* imgsA, const uint8_t* imgsB, int B,
  * identical to vo_pairs_run_device on the same pairs.  out: HOST array [F-1]. */
 int vo_sequence_run_device(vo_ctx* ctx, const uint8_t* imgs_dev, int F, int w, int h, int stride,
                            const double K[9], double ratio, vo_pair_result* out_host, void* stream);
+
+/* Row T for a whole wave of pairs: replaces the per-match loop of vo.py:91-93 (2 x N calls of
+ * VisualOdometry.triangulate, libs/vo_utils.py:148-164, per frame).  After a vo_pairs_run* / vo_sequence_run* call of
+ * at most max_pairs pairs, the ratio-test matches (q1, q2) of those pairs are still on the device; this triangulates
+ * ALL matches of the first P pairs in one launch.  P1, P2: host float64 [P][12] row-major projection matrices of
+ * every pair, K @ prev_pose[:3] and K @ cur_pose[:3] as libs/vo_utils.py:153-157 forms them (the caller chains the
+ * poses, vo.py:80; visual_slam_amd/trajectory.py does).  Outputs (host): X float32 [cap][3], the points already
+ * divided by their 4th coordinate in float32 like libs/vo_utils.py:161; q1, q2 float32 [cap][2] (either may be
+ * NULL); offsets int64 [P+1]: pair p owns rows offsets[p] .. offsets[p+1]-1, in ascending queryIdx.  A pair whose
+ * status in that call's vo_pair_result is not VO_OK (no pose to chain) owns no rows. */
+int vo_pairs_triangulate(vo_ctx* ctx, int P, const double* P1, const double* P2, float* X, float* q1, float* q2,
+                         long cap, int64_t* offsets);
 
 /* Same with host images (adds the H2D copy). */
 int vo_sequence_run(vo_ctx* ctx, const uint8_t* imgs, int F, int w, int h, int stride,

@@ -300,3 +300,68 @@ def test_device_frames_with_stride_and_odd_base(K02):
         assert (dense["status"] == 0).all()
     finally:
         c.close()
+
+
+def test_get_matches_one_call_equals_the_three_calls(ctx, kitti02, kitti09):
+    """vo_get_matches (both frames in one launch wave, matched on the device) == detectAndCompute x2 + knnMatch + ratio."""
+    for a, b in ((kitti02[0], kitti02[1]), (kitti09[0], kitti09[1])):
+        from visual_slam_amd import _lib
+        c = _lib.Context(max_w=a.shape[1], max_h=a.shape[0])
+        k1, f1 = c.orb_detect_compute(a); k2, f2 = c.orb_detect_compute(b)
+        qi, ti, _, _ = c.match_knn2_ratio(f1, f2, 0.45)
+        q1, q2 = c.get_matches(a, b, 0.45)
+        c.close()
+        assert len(q1) == len(qi) > 100
+        assert np.array_equal(q1, np.stack([k1["x"][qi], k1["y"][qi]], 1)) and np.array_equal(q2, np.stack([k2["x"][ti], k2["y"][ti]], 1))
+    flat = np.full_like(kitti02[0], 77)
+    with pytest.raises(_lib.VoError) as e:
+        ctx.get_matches(kitti02[0], flat)
+    assert e.value.code == _lib.VO_ERR_TOO_FEW
+
+
+def _check_points(oracle, K, poses_prev, poses_cur, X, q1, q2, off):
+    worst = 0.0
+    for p in range(len(off) - 1):
+        a, b = int(off[p]), int(off[p + 1])
+        if a == b:
+            continue
+        Xo = oracle.triangulate_f32(K @ poses_prev[p][:3], K @ poses_cur[p][:3], q1[a:b], q2[a:b])
+        ref = (Xo / Xo[3])[:3].T                                    # libs/vo_utils.py:161-164 in float32
+        worst = max(worst, float(np.abs(X[a:b] - ref).max() / np.abs(ref).max()))
+    return worst
+
+
+def test_batched_triangulation_sequence_and_pairs(oracle, kitti02, K02):
+    """Row T in the batched path (vo.py:80-93): every match of every pair in ONE launch, against the oracle's
+    triangulatePoints on the same correspondences and projection matrices, relative error < 1e-5 (north star)."""
+    from conftest import GOLDEN
+    from visual_slam_amd import _lib, synth, trajectory as tj
+    from visual_slam_amd.vo_utils import VisualOdometry
+    # (a) the bundled KITTI 02 frames as a sequence, poses chained as vo.py:80 does
+    vo = VisualOdometry(os.path.join(GOLDEN, "kitti02"), False)
+    out = tj.run_sequence(vo, triangulate=True, wave=2, chunk=1)     # two pose waves, three lanes
+    off = out["point_offsets"]
+    assert len(off) == 4 and off[-1] == len(out["points"]) == out["results"]["n_match"].sum()
+    prevs = [np.eye(4)] + out["poses"][:-1]
+    assert _check_points(oracle, vo.K, prevs, out["poses"], out["points"], out["q1"], out["q2"], off) < 1e-5
+    # the drop-in's per-match call gives the same rows (vo.py:92)
+    p0 = vo.triangulate(out["q1"][0], out["q2"][0], np.eye(4), out["poses"][0])
+    assert np.allclose(p0, out["points"][0], rtol=1e-6, atol=0)
+    # (b) 96 independent synthetic pairs: prev = identity, cur = inv(T) per pair
+    A, B = synth.make_batch(range(500, 596), workers=4)
+    K = synth.K_KITTI02
+    ctx = _lib.Context(max_w=1241, max_h=376, chunk_pairs=16, max_pairs=96)
+    res = ctx.pairs_run(A, B, K)
+    assert (res["status"] == 0).all()
+    curs = [np.linalg.inv(t) for t in res["T"]]
+    P1 = np.array([K @ np.eye(4)[:3]] * 96); P2 = np.array([K @ c[:3] for c in curs])
+    X, q1, q2, off = ctx.pairs_triangulate(P1, P2)
+    assert np.array_equal(np.diff(off), res["n_match"]) and len(X) == off[-1] > 96 * 100
+    assert _check_points(oracle, K, [np.eye(4)] * 96, curs, X, q1, q2, off) < 1e-5
+    # a failed pair owns no rows
+    flat = np.full_like(A[0], 50)
+    res = ctx.pairs_run(np.stack([A[0], flat, A[1]]), np.stack([B[0], flat, B[1]]), K)
+    assert res["status"][1] != 0
+    X2, _, _, off2 = ctx.pairs_triangulate(P1[:3], P2[[0, 1, 1]])
+    assert off2[1] == off2[2] and off2[3] - off2[2] == res["n_match"][2] and np.array_equal(X2[: off2[1]], X[: off[1]])
+    ctx.close()

@@ -36,7 +36,7 @@ PAIR_DTYPE = np.dtype([("T", "<f8", (4, 4)), ("n_kp1", "<i4"), ("n_kp2", "<i4"),
 EXPORTS = [
     "vo_default_orb_params", "vo_ctx_create", "vo_ctx_destroy", "vo_last_error", "vo_orb_detect_compute", "vo_match_knn2_ratio",
     "vo_match_knn2", "vo_find_essential_ransac", "vo_recover_pose", "vo_triangulate", "vo_pairs_run_device", "vo_pairs_run", "vo_sequence_run_device", "vo_sequence_run", "vo_ba_plan_create", "vo_ba_plan_destroy", "vo_ba_pass_device", "vo_ba_pass",
-    "vo_match_knn2_ratio_noalloc", "vo_debug_read", "vo_set_debug_stop", "vo_set_kernel_timing", "vo_get_kernel_timing",
+    "vo_match_knn2_ratio_noalloc", "vo_get_matches", "vo_pairs_triangulate", "vo_debug_read", "vo_set_debug_stop", "vo_set_kernel_timing", "vo_get_kernel_timing",
 ]
 
 _lib = None
@@ -71,6 +71,8 @@ def load():
     lib.vo_find_essential_ransac.argtypes = [vp, vp, vp, i, vp, d, d, i, vp, vp, vp]
     lib.vo_recover_pose.argtypes = [vp, vp, vp, vp, i, vp, d, vp, vp, vp]
     lib.vo_triangulate.argtypes = [vp, vp, vp, vp, vp, i, vp]
+    lib.vo_get_matches.argtypes = [vp, vp, vp, i, i, i, d, vp, vp, i, vp]
+    lib.vo_pairs_triangulate.argtypes = [vp, i, vp, vp, vp, vp, vp, C.c_long, vp]
     lib.vo_pairs_run_device.argtypes = [vp, vp, vp, i, i, i, i, vp, d, vp, vp]
     lib.vo_pairs_run.argtypes = [vp, vp, vp, i, i, i, i, vp, d, vp]
     lib.vo_sequence_run_device.argtypes = [vp, vp, i, i, i, i, vp, d, vp, vp]
@@ -119,6 +121,7 @@ class Context:
             raise VoError(rc, msg)
         self.kp_cap = self.params.nfeatures + 1024
         self.device = device
+        self.chunk_pairs, self.max_pairs = chunk_pairs, max(max_pairs, chunk_pairs)
 
     def close(self):
         if getattr(self, "h", None):
@@ -193,6 +196,35 @@ class Context:
         X4 = np.zeros((4, n), np.float32)
         self._check(self.lib.vo_triangulate(self.h, _ptr(P1), _ptr(P2), _ptr(x1), _ptr(x2), n, _ptr(X4)))
         return X4
+
+    def get_matches(self, img_prev, img_cur, ratio=0.45):
+        """get_matches of libs/vo_utils.py:83-110 in one call: (q1, q2) float32 (N,2)."""
+        a = np.ascontiguousarray(img_prev, np.uint8); b = np.ascontiguousarray(img_cur, np.uint8)
+        if a.ndim != 2 or a.shape != b.shape:
+            raise ValueError("expected two single-channel 8-bit images of one size")
+        h, w = a.shape
+        q1 = np.zeros((self.kp_cap, 2), np.float32); q2 = np.zeros((self.kp_cap, 2), np.float32)
+        n = C.c_int(0)
+        self._check(self.lib.vo_get_matches(self.h, _ptr(a), _ptr(b), w, h, w, float(ratio), _ptr(q1), _ptr(q2), self.kp_cap, C.byref(n)))
+        return q1[: n.value].copy(), q2[: n.value].copy()
+
+    def pairs_triangulate(self, P1, P2, want_points2d=True):
+        """All ratio-test matches of the first len(P1) pairs of the last pairs_run* / sequence_run* wave, triangulated in one
+        launch with per-pair projection matrices P1[p], P2[p] (3x4 float64).  Returns (X float32 (N,3), q1 (N,2), q2 (N,2),
+        offsets int64 (P+1)); q1, q2 are None unless want_points2d."""
+        P1 = np.ascontiguousarray(P1, np.float64).reshape(-1, 12); P2 = np.ascontiguousarray(P2, np.float64).reshape(-1, 12)
+        P = len(P1)
+        if len(P2) != P:
+            raise ValueError("P1 and P2 must hold one matrix per pair")
+        cap = P * self.kp_cap
+        X = np.zeros((cap, 3), np.float32)
+        q1 = np.zeros((cap, 2), np.float32) if want_points2d else None
+        q2 = np.zeros((cap, 2), np.float32) if want_points2d else None
+        off = np.zeros(P + 1, np.int64)
+        self._check(self.lib.vo_pairs_triangulate(self.h, P, _ptr(P1), _ptr(P2), _ptr(X), _ptr(q1) if want_points2d else None,
+                                                  _ptr(q2) if want_points2d else None, cap, _ptr(off)))
+        n = int(off[-1])
+        return X[:n].copy(), (q1[:n].copy() if want_points2d else None), (q2[:n].copy() if want_points2d else None), off
 
     # ---- batched pairs
     def pairs_run(self, imgsA, imgsB, K, ratio=0.45):

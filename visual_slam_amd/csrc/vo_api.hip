@@ -2,6 +2,7 @@
 // (declared in include/vo_mi355.h; each stands behind one cv2 call of
 // /root/reference/libs/vo_utils.py).  No CPU fallback: every entry point runs HIP kernels.
 #include <algorithm>
+#include <cstddef>
 #include <cstring>
 #include <functional>
 
@@ -529,8 +530,15 @@ static int propagate_geometry(vo_ctx* c) {
 // RANSAC rounds are issued only after detect + match of batch b+1 have been enqueued, so they overlap them; the pair
 // arrays the two stages share exist twice (vo_ctx::slot).  In the timing mode everything runs on ONE stream, one
 // kernel at a time (HIP events bracket every launch).
+// Host-image entry points pass a Stager: before the chunks of pairs [p0, p0 + pairs) of a batch are enqueued, the lanes
+// are drained (they may still read the staging buffer) and prepare(first_pair, n) copies the next n pairs' frames up.
+struct Stager {
+    std::function<int(int, int)> prepare;
+    int pairs = 0;
+};
+
 static int run_batches(vo_ctx* c, int B, int cp, const double K[9], vo_pair_result* out, hipStream_t user,
-                       const std::function<int(vo_ctx*, hipStream_t, int, int, int)>& chunk) {
+                       const std::function<int(vo_ctx*, hipStream_t, int, int, int)>& chunk, const Stager* stg = nullptr) {
     const bool serial = c->timing;
     const int nl = serial ? 1 : 1 + (int)c->lanes.size();
     auto lane = [&](int i) { return i == 0 ? c : c->lanes[i - 1]; };
@@ -553,6 +561,12 @@ static int run_batches(vo_ctx* c, int B, int cp, const double K[9], vo_pair_resu
         c->slot = slot;
         unsigned used = 0;
         for (int p0 = 0; p0 < Pb; p0 += cp, nchunk++) {
+            if (stg && p0 % stg->pairs == 0) {
+                for (hipStream_t q : lst)
+                    if (hipStreamSynchronize(q) != hipSuccess) return drain(vo_fail(c, VO_ERR_HIP, "hipStreamSynchronize failed"));
+                rc = stg->prepare(b0 + p0, std::min(stg->pairs, Pb - p0));
+                if (rc != VO_OK) return drain(rc);
+            }
             const int li = nchunk % nl;
             vo_ctx* L = lane(li);
             L->slot = slot;
@@ -637,43 +651,151 @@ int vo_sequence_run_device(vo_ctx* c, const uint8_t* imgs, int F, int w, int h, 
     });
 }
 
+// get_matches (libs/vo_utils.py:83-110) in one call: both frames go up together, are extracted in one launch wave and
+// matched on the device; only the matched pixel positions come back.
+int vo_get_matches(vo_ctx* c, const uint8_t* imgA, const uint8_t* imgB, int w, int h, int stride, double ratio, float* q1, float* q2, int cap, int* n) {
+    if (!c) return VO_ERR_INVALID;
+    if (!imgA || !imgB || !n || w <= 0 || h <= 0 || stride < w || cap < 0) return vo_fail(c, VO_ERR_INVALID, "vo_get_matches: bad arguments");
+    HIP_TRY(c, hipSetDevice(c->device));
+    int rc = vo_build_geometry(c, w, h);
+    if (rc != VO_OK) return rc;
+    propagate_geometry(c);
+    const long fs = (long)w * h;
+    if ((size_t)(2 * fs) > c->d_img.bytes) return vo_fail(c, VO_ERR_CAPACITY, "vo_get_matches: staging buffer too small");
+    uint8_t* dA = (uint8_t*)c->d_img.p;
+    HIP_TRY(c, copy_frames_h2d(dA, imgA, w, stride, (size_t)h));
+    HIP_TRY(c, copy_frames_h2d(dA + fs, imgB, w, stride, (size_t)h));
+    hipStream_t st = c->stream;
+    c->slot = 0; c->last_lane = 0; c->last_pairs = 1;
+    FrameSrc src{dA, dA + fs, 1, w, fs};
+    c->last_src = src; c->last_frames = 2;
+    rc = vo_launch_detect(c, src, 2, st);
+    if (rc != VO_OK) return rc;
+    rc = vo_launch_match_impl(c, 1, 1, ratio, 0, nullptr, st);
+    if (rc != VO_OK) return rc;
+    int hs[2] = {0, 0};
+    HIP_TRY(c, hipMemcpyAsync(&hs[0], c->nmatch(), 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipMemcpyAsync(&hs[1], c->pair_status(), 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipStreamSynchronize(st));
+    if (c->timing) kt_collect(c);
+    *n = 0;
+    if (hs[1] == VO_ERR_TOO_FEW) return vo_fail(c, VO_ERR_TOO_FEW, "knnMatch(k=2) needs at least 2 train descriptors");
+    if (hs[1] != VO_OK) return vo_fail(c, hs[1], "vo_get_matches: keypoint list overflow (too many response ties)");
+    *n = hs[0];
+    if (hs[0] > cap) return vo_fail(c, VO_ERR_CAPACITY, "vo_get_matches: output capacity too small");
+    if (hs[0] && q1) HIP_TRY(c, hipMemcpy(q1, c->q1(), (size_t)hs[0] * 8, hipMemcpyDeviceToHost));
+    if (hs[0] && q2) HIP_TRY(c, hipMemcpy(q2, c->q2(), (size_t)hs[0] * 8, hipMemcpyDeviceToHost));
+    return VO_OK;
+}
+
+// Row T for a whole wave of pairs (vo.py:80-93): the ratio-test matches of the last pose wave are still on the device;
+// pair p is triangulated with its own P1[p], P2[p] (the caller chains the poses: K @ prev_pose[:3], K @ cur_pose[:3]).
+int vo_pairs_triangulate(vo_ctx* c, int P, const double* P1, const double* P2, float* X, float* q1, float* q2, long cap, int64_t* offsets) {
+    if (!c) return VO_ERR_INVALID;
+    if (!P1 || !P2 || !offsets || P < 0 || cap < 0) return vo_fail(c, VO_ERR_INVALID, "vo_pairs_triangulate: bad arguments");
+    if (P > c->last_pairs) return vo_fail(c, VO_ERR_INVALID, "vo_pairs_triangulate: more pairs than the last pose wave held");
+    offsets[0] = 0;
+    if (P == 0) return VO_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    std::vector<int> nm(P), stt(P);
+    HIP_TRY(c, hipMemcpy(nm.data(), c->nmatch(), (size_t)P * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy2D(stt.data(), 4, (const uint8_t*)c->d_result.p + offsetof(vo_pair_result, status), sizeof(vo_pair_result), 4, P, hipMemcpyDeviceToHost));
+    std::vector<long> off(P + 1, 0);
+    for (int p = 0; p < P; p++) off[p + 1] = off[p] + (stt[p] == VO_OK ? nm[p] : 0);   // a failed pair (no pose to chain) has no points
+    for (int p = 0; p <= P; p++) offsets[p] = off[p];
+    const long N = off[P];
+    if (N > cap) return vo_fail(c, VO_ERR_CAPACITY, "vo_pairs_triangulate: output capacity too small");
+    if (N == 0) return VO_OK;
+    if (!X) return vo_fail(c, VO_ERR_INVALID, "vo_pairs_triangulate: X is null");
+    const size_t bPm = ((size_t)P * 24 * 8 + 255) / 256 * 256, bOff = ((size_t)(P + 1) * 8 + 255) / 256 * 256, bX = ((size_t)N * 12 + 255) / 256 * 256,
+                 bQ = ((size_t)N * 8 + 255) / 256 * 256;
+    const size_t need = bPm + bOff + bX + 2 * bQ;
+    if (c->d_tri.bytes < need) {
+        dev_free(c->d_tri);
+        ALLOC(c, c->d_tri, need + need / 2);
+    }
+    uint8_t* base = (uint8_t*)c->d_tri.p;
+    double* dPm = (double*)base;
+    long* dOff = (long*)(base + bPm);
+    float* dX = (float*)(base + bPm + bOff);
+    float2* dq1 = (float2*)(base + bPm + bOff + bX);
+    float2* dq2 = (float2*)(base + bPm + bOff + bX + bQ);
+    std::vector<double> Pm((size_t)P * 24);
+    for (int p = 0; p < P; p++) {
+        memcpy(&Pm[(size_t)p * 24], P1 + (size_t)p * 12, 96);
+        memcpy(&Pm[(size_t)p * 24 + 12], P2 + (size_t)p * 12, 96);
+    }
+    HIP_TRY(c, hipMemcpyAsync(dPm, Pm.data(), Pm.size() * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(c, hipMemcpyAsync(dOff, off.data(), off.size() * 8, hipMemcpyHostToDevice, st));
+    int rc = vo_launch_triangulate_pairs(c, P, dPm, dOff, dX, q1 ? dq1 : nullptr, q2 ? dq2 : nullptr, st);
+    if (rc != VO_OK) return rc;
+    HIP_TRY(c, hipMemcpyAsync(X, dX, (size_t)N * 12, hipMemcpyDeviceToHost, st));
+    if (q1) HIP_TRY(c, hipMemcpyAsync(q1, dq1, (size_t)N * 8, hipMemcpyDeviceToHost, st));
+    if (q2) HIP_TRY(c, hipMemcpyAsync(q2, dq2, (size_t)N * 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipStreamSynchronize(st));   // Pm / off are stack-owned: the copies must have left them
+    return VO_OK;
+}
+
 int vo_sequence_run(vo_ctx* c, const uint8_t* imgs, int F, int w, int h, int stride, const double K[9], double ratio, vo_pair_result* out) {
     if (!c) return VO_ERR_INVALID;
-    if (!imgs || F < 0 || stride < w) return vo_fail(c, VO_ERR_INVALID, "vo_sequence_run: bad arguments");
+    if (!imgs || !K || !out || F < 0 || stride < w) return vo_fail(c, VO_ERR_INVALID, "vo_sequence_run: bad arguments");
     if (F < 2) return VO_OK;
     HIP_TRY(c, hipSetDevice(c->device));
-    // stage through device memory: up to 2*chunk_pairs frames at a time, consecutive stages share one frame
+    int rc = vo_build_geometry(c, w, h);
+    if (rc != VO_OK) return rc;
+    propagate_geometry(c);
+    // frames are staged through device memory one chunk per lane at a time (n pairs = n + 1 frames; pieces share one frame)
     const long fs = (long)w * h;
-    const int cap = (int)std::min<long>(2L * c->chunk_pairs * (1 + (long)c->lanes.size()), (long)(c->d_img.bytes / fs));
-    if (cap < 2) return vo_fail(c, VO_ERR_CAPACITY, "vo_sequence_run: staging buffer too small");
-    for (int f0 = 0; f0 < F - 1; f0 += cap - 1) {
-        const int nf = std::min(cap, F - f0);
-        HIP_TRY(c, copy_frames_h2d(c->d_img.p, imgs + (long)f0 * stride * h, w, stride, (size_t)h * nf));
-        int rc = vo_sequence_run_device(c, (const uint8_t*)c->d_img.p, nf, w, h, w, K, ratio, out + f0, nullptr);
-        if (rc != VO_OK) return rc;
-    }
-    return VO_OK;
+    const int cp = std::min(c->chunk_pairs, 2 * c->chunk_pairs - 1);
+    Stager stg;
+    stg.pairs = (int)std::min<long>((long)cp * (1 + (long)c->lanes.size()), (long)(c->d_img.bytes / fs) - 1);
+    if (stg.pairs < cp) return vo_fail(c, VO_ERR_CAPACITY, "vo_sequence_run: staging buffer too small");
+    stg.pairs -= stg.pairs % cp;
+    stg.prepare = [&](int first, int n) {
+        HIP_TRY(c, copy_frames_h2d(c->d_img.p, imgs + (long)first * stride * h, w, stride, (size_t)h * (n + 1)));
+        return (int)VO_OK;
+    };
+    return run_batches(c, F - 1, cp, K, out, nullptr, [&](vo_ctx* L, hipStream_t st, int b0, int p0, int Pc) {
+        const uint8_t* first = (const uint8_t*)c->d_img.p + (long)(p0 % stg.pairs) * fs;
+        FrameSrc src{first, first, Pc + 1, w, fs};
+        L->last_src = src; L->last_frames = Pc + 1;
+        int r = vo_launch_detect(L, src, Pc + 1, st);
+        if (r != VO_OK) return r;
+        return vo_launch_match_impl(L, Pc, 1, ratio, p0, nullptr, st);
+    }, &stg);
 }
 
 int vo_pairs_run(vo_ctx* c, const uint8_t* imgsA, const uint8_t* imgsB, int B, int w, int h, int stride, const double K[9], double ratio,
                  vo_pair_result* out) {
     if (!c) return VO_ERR_INVALID;
-    if (!imgsA || !imgsB || B < 0 || stride < w) return vo_fail(c, VO_ERR_INVALID, "vo_pairs_run: bad arguments");
+    if (!imgsA || !imgsB || !K || !out || B < 0 || stride < w) return vo_fail(c, VO_ERR_INVALID, "vo_pairs_run: bad arguments");
+    if (B == 0) return VO_OK;
     HIP_TRY(c, hipSetDevice(c->device));
-    // stage through device memory in super-batches of chunk_pairs pairs (d_img holds 2*chunk_pairs frames)
+    int rc = vo_build_geometry(c, w, h);
+    if (rc != VO_OK) return rc;
+    propagate_geometry(c);
+    // frames are staged through device memory one chunk per lane at a time: A frames in the first half of d_img, B in the second
     const long fs = (long)w * h;
-    const int stage = c->chunk_pairs * (1 + (int)c->lanes.size());   // d_img holds one chunk per lane
-    for (int b0 = 0; b0 < B; b0 += stage) {
-        const int Pc = std::min(stage, B - b0);
-        if ((size_t)(2 * Pc * fs) > c->d_img.bytes) return vo_fail(c, VO_ERR_CAPACITY, "vo_pairs_run: staging buffer too small");
-        uint8_t* dA = (uint8_t*)c->d_img.p;
-        uint8_t* dB = dA + (long)Pc * fs;
-        HIP_TRY(c, copy_frames_h2d(dA, imgsA + (long)b0 * stride * h, w, stride, (size_t)h * Pc));
-        HIP_TRY(c, copy_frames_h2d(dB, imgsB + (long)b0 * stride * h, w, stride, (size_t)h * Pc));
-        int rc = vo_pairs_run_device(c, dA, dB, Pc, w, h, w, K, ratio, out + b0, nullptr);
-        if (rc != VO_OK) return rc;
-    }
-    return VO_OK;
+    Stager stg;
+    stg.pairs = (int)std::min<long>((long)c->chunk_pairs * (1 + (long)c->lanes.size()), (long)(c->d_img.bytes / fs) / 2);
+    if (stg.pairs < c->chunk_pairs) return vo_fail(c, VO_ERR_CAPACITY, "vo_pairs_run: staging buffer too small");
+    stg.pairs -= stg.pairs % c->chunk_pairs;
+    uint8_t* dA = (uint8_t*)c->d_img.p;
+    uint8_t* dB = dA + (long)stg.pairs * fs;
+    stg.prepare = [&](int first, int n) {
+        HIP_TRY(c, copy_frames_h2d(dA, imgsA + (long)first * stride * h, w, stride, (size_t)h * n));
+        HIP_TRY(c, copy_frames_h2d(dB, imgsB + (long)first * stride * h, w, stride, (size_t)h * n));
+        return (int)VO_OK;
+    };
+    return run_batches(c, B, c->chunk_pairs, K, out, nullptr, [&](vo_ctx* L, hipStream_t st, int b0, int p0, int Pc) {
+        const long q = p0 % stg.pairs;
+        FrameSrc src{dA + q * fs, dB + q * fs, Pc, w, fs};
+        L->last_src = src; L->last_frames = 2 * Pc;
+        int r = vo_launch_detect(L, src, 2 * Pc, st);
+        if (r != VO_OK) return r;
+        return vo_launch_match_impl(L, Pc, Pc, ratio, p0, nullptr, st);
+    }, &stg);
 }
 
 // -------------------------------------------------------------------- stage read-back

@@ -751,6 +751,37 @@ __global__ __launch_bounds__(256) void k_triangulate(const double* __restrict__ 
     for (int k = 0; k < 4; k++) X4[(long)k * n + i] = (float)X[k];
 }
 
+// All ratio-test matches of a wave of pairs in ONE launch (the loop of vo.py:91-93 calls triangulate twice per match):
+// pair p uses its own projection matrices Pm[p] = (P1, P2) = (K @ prev_pose[:3], K @ cur_pose[:3]); the result is
+// dehomogenised as the reference does it, in float32 (points_4D / points_4D[3], libs/vo_utils.py:161), and written
+// compacted at offsets[p] + i together with the matched pixel positions.
+__global__ __launch_bounds__(256) void k_triangulate_pairs(const double* __restrict__ Pm, const long* __restrict__ offsets, int kp_cap,
+                                                           const float2* __restrict__ q1, const float2* __restrict__ q2,
+                                                           float* __restrict__ X3, float2* __restrict__ q1o, float2* __restrict__ q2o) {
+    const int p = blockIdx.y;
+    const long o0 = offsets[p];
+    const int n = (int)(offsets[p + 1] - o0);
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    double P1[12], P2[12], X[4];
+    for (int k = 0; k < 12; k++) { P1[k] = Pm[p * 24 + k]; P2[k] = Pm[p * 24 + 12 + k]; }
+    const float2 a = q1[(long)p * kp_cap + i], b = q2[(long)p * kp_cap + i];
+    triangulate_one(P1, P2, (double)a.x, (double)a.y, (double)b.x, (double)b.y, X);
+    const float w = (float)X[3];
+    X3[(o0 + i) * 3 + 0] = (float)X[0] / w;
+    X3[(o0 + i) * 3 + 1] = (float)X[1] / w;
+    X3[(o0 + i) * 3 + 2] = (float)X[2] / w;
+    if (q1o) q1o[o0 + i] = a;
+    if (q2o) q2o[o0 + i] = b;
+}
+
+int vo_launch_triangulate_pairs(vo_ctx* c, int P, const double* dPm, const long* doffsets, float* dX3, float2* dq1, float2* dq2, hipStream_t st) {
+    hipLaunchKernelGGL(k_triangulate_pairs, dim3((c->kp_cap + 255) / 256, P), dim3(256), 0, st, dPm, doffsets, c->kp_cap, (const float2*)c->q1(),
+                       (const float2*)c->q2(), dX3, dq1, dq2);
+    HIP_TRY(c, hipGetLastError());
+    return VO_OK;
+}
+
 // ------------------------------------------------------------------ host
 static NormK make_normk(const double K[9]) {
     const double fx = K[0], fy = K[4], cx = K[2], cy = K[5];

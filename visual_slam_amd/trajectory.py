@@ -128,29 +128,61 @@ def direction_angle(ta, tb):
     return float(np.arccos(np.clip(c, -1, 1)))
 
 
-def run_sequence(vo, max_frames=None):
-    """The reference's main loop (vo.py:48-190) without display and BA, on the batched GPU path:
-    every consecutive pair of vo.image_paths goes through one `sequence_run` call.
+def projection_pairs(K, poses, start=None):
+    """(P1, P2) float64 (N,3,4) that `VisualOdometry.triangulate(q1, q2, prev_pose, cur_pose)` forms for every frame of the
+    loop (vo.py:92 with libs/vo_utils.py:153-157): P1 = K @ prev_pose[:3], P2 = K @ cur_pose[:3], where prev_pose is the
+    chained pose before the pair (identity, or `start`, for the first) and cur_pose the one after it."""
+    K = np.asarray(K, np.float64)
+    prev = np.eye(4) if start is None else np.array(start, np.float64)
+    P1, P2 = [], []
+    for cur in poses:
+        P1.append(K @ prev[:3, :])
+        P2.append(K @ np.asarray(cur, np.float64)[:3, :])
+        prev = cur
+    return np.array(P1).reshape(-1, 3, 4), np.array(P2).reshape(-1, 3, 4)
 
-    Returns a dict: transfs (N,4,4), poses (list of N (4,4)), estimated_path (N,3), gt_path
-    ((N,3) or None), gt_error (mean, or None), results (the raw per-pair records)."""
-    from . import vo_utils
+
+def run_sequence(vo, max_frames=None, triangulate=False, wave=256, chunk=64):
+    """The reference's main loop (vo.py:48-190) without display and BA, on the batched GPU path: the consecutive pairs of
+    vo.image_paths go through `sequence_run` in waves of `wave` pairs; the poses are chained on the host exactly as
+    vo.py:77-81 does; with triangulate=True every match of every pair is triangulated (vo.py:91-93) by ONE
+    `pairs_triangulate` launch per wave instead of 2 N Python -> cv2 calls per frame.
+
+    Returns a dict: transfs (N,4,4), poses (list of N (4,4)), estimated_path (N,3), gt_path ((N,3) or None), gt_error
+    (mean, or None), results (the raw per-pair records) and, with triangulate, points (M,3) float32 = the reference's
+    Q list, q1 / q2 (M,2), point_offsets (N+1): pair i owns rows point_offsets[i] .. point_offsets[i+1]-1."""
+    from . import _lib, vo_utils
     paths = vo.image_paths if max_frames is None else vo.image_paths[:max_frames]
     imgs = np.stack([vo_utils._imread_gray(p) for p in paths])
-    from . import _lib
     npairs = len(imgs) - 1
-    ctx = _lib.Context(max_w=imgs.shape[2], max_h=imgs.shape[1], chunk_pairs=max(1, min(64, npairs)), max_pairs=max(1, npairs), nfeatures=3000)
+    wave = max(1, min(wave, npairs))
+    ctx = _lib.Context(max_w=imgs.shape[2], max_h=imgs.shape[1], chunk_pairs=max(1, min(chunk, wave)), max_pairs=wave, nfeatures=3000)
+    res_all, poses, pts, q1s, q2s, offs = [], [], [], [], [], [0]
     try:
-        res = ctx.sequence_run(imgs, vo.K)
+        cur = np.eye(4)
+        for w0 in range(0, npairs, wave):
+            w1 = min(w0 + wave, npairs)
+            res = ctx.sequence_run(imgs[w0:w1 + 1], vo.K)
+            bad = np.nonzero(res["status"] != 0)[0]
+            if len(bad):
+                raise RuntimeError("pair %d failed with status %d" % (w0 + int(bad[0]), int(res["status"][bad[0]])))
+            wposes = chain_poses(res["T"].reshape(-1, 4, 4), start=cur)
+            if triangulate:
+                P1, P2 = projection_pairs(vo.K, wposes, start=cur)
+                X, q1, q2, off = ctx.pairs_triangulate(P1, P2)
+                pts.append(X); q1s.append(q1); q2s.append(q2)
+                offs.extend((off[1:] + offs[-1]).tolist())
+            cur = wposes[-1]
+            poses.extend(wposes)
+            res_all.append(res)
     finally:
         ctx.close()
-    bad = np.nonzero(res["status"] != 0)[0]
-    if len(bad):
-        raise RuntimeError("pair %d failed with status %d" % (int(bad[0]), int(res["status"][bad[0]])))
+    res = np.concatenate(res_all)
     transfs = res["T"].reshape(-1, 4, 4)
-    poses = chain_poses(transfs)
     est = estimated_path(poses)
     out = {"transfs": transfs, "poses": poses, "estimated_path": est, "gt_path": None, "gt_error": None, "results": res}
+    if triangulate:
+        out.update(points=np.concatenate(pts), q1=np.concatenate(q1s), q2=np.concatenate(q2s), point_offsets=np.array(offs, np.int64))
     if vo.gt_poses:
         g = gt_path(vo.gt_poses, 1, len(poses))
         out["gt_path"] = g

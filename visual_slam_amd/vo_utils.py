@@ -101,14 +101,17 @@ class VisualOdometry():
             img1 = _imread_gray(self.image_paths[i - 1])
             img2 = _imread_gray(self.image_paths[i])
         ctx = self._context(*img1.shape)
-        kps1, features1 = ctx.orb_detect_compute(img1)
-        kps2, features2 = ctx.orb_detect_compute(img2)
-        if len(kps2) < 2:
-            # knnMatch returns fewer than 2 neighbours -> `for m,n in matches` raises in the reference
-            raise ValueError("not enough values to unpack (expected 2 neighbours per match)")
-        qidx, tidx, _, _ = ctx.match_knn2_ratio(features1, features2, ratio)
-        q1 = np.float32([(kps1["x"][m], kps1["y"][m]) for m in qidx])
-        q2 = np.float32([(kps2["x"][m], kps2["y"][m]) for m in tidx])
+        # detectAndCompute x2 + knnMatch + ratio loop + the two list comprehensions (:94-108) are ONE library call:
+        # both frames are extracted in one launch wave and matched on the device, only q1 / q2 come back
+        try:
+            q1, q2 = ctx.get_matches(img1, img2, ratio)
+        except _lib.VoError as e:
+            if e.code == _lib.VO_ERR_TOO_FEW:
+                # knnMatch returns fewer than 2 neighbours -> `for m,n in matches` raises in the reference
+                raise ValueError("not enough values to unpack (expected 2 neighbours per match)") from e
+            raise
+        if len(q1) == 0:
+            return np.float32([]), np.float32([])     # np.float32([]) has shape (0,), as in the reference
         return q1, q2
 
     def get_pose(self, q1, q2):
