@@ -33,8 +33,9 @@ HBM_PEAK_GBS = 8000.0
 # matcher: one Hamming distance = a 256-long i8 dot product on the matrix cores = 512 ops;
 # dense i8 MFMA peak = 2 x bf16 = 256 CU x 4 SIMD x 2048 ops/clk x 2.4 GHz (MI355X_MICROARCH.md, Matrix cores)
 MFMA_I8_PEAK_TOPS = 256 * 4 * 2048 * 2.4e9 / 1e12
-# VALU issue: 256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz = 39.3 T lane-ops/s = 0.614 T wave64-instructions/s (full rate)
-VALU_PEAK_WAVE_INSTS = 256 * 4 * 2.4e9 / 4
+# VALU issue (MI355X_MICROARCH.md: a wave64 VALU instruction issues over 2 cycles, 32 lanes per cycle and SIMD):
+# 256 CU x 4 SIMD x 2.4 GHz / 2 = 1.229 T wave64-instructions/s = 78.6 T lane-ops/s at full rate
+VALU_PEAK_WAVE_INSTS = 256 * 4 * 2.4e9 / 2
 TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r2_pmc_hbm_traffic.json")
 VALU_FILE = os.path.join(ROOT, "profiles", "r2_pmc_valu.json")
 KITTI_DIR = os.path.join(ROOT, "tests", "golden", "kitti02")
@@ -101,7 +102,7 @@ def valu_roofline(kernel, frames_per_launch, avg_launch_s, P, w, h):
     return {"wave_insts_per_launch": int(insts), "insts_per_px": round(insts * 64 / (P * frames_per_launch), 2),
             "achieved": round(achieved / 1e9, 2), "peak": round(VALU_PEAK_WAVE_INSTS / 1e9, 1), "unit": "G wave64-instructions/s",
             "frac": round(achieved / VALU_PEAK_WAVE_INSTS, 4), "valu_busy": t["kernels"][kernel].get("valu_busy"),
-            "note": "peak = every SIMD issuing one full-rate VALU instruction per 4 cycles; v_min/v_max/v_cmp/v_perm issue at about half that rate (DESIGN.md 3.2)"}
+            "note": "peak = every SIMD issuing one full-rate wave64 VALU instruction per 2 cycles; v_min/v_max/v_cmp/v_perm and all VOP3 integer ops issue at half that rate (DESIGN.md 3.2), which is most of this kernel; valu_busy = fraction of SIMD-cycles with the VALU executing (SQ_ACTIVE_INST_VALU / (8 x SQ_BUSY_CYCLES))"}
 
 
 def cpu_model():

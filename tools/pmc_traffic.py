@@ -17,7 +17,7 @@ def per_kernel(path, counter):
 
 f, nf = per_kernel(sys.argv[1], "FETCH_SIZE")
 w, nw = per_kernel(sys.argv[2], "WRITE_SIZE")
-out = {"meta": {"_about": sys.argv[4], "frames_per_launch": int(sys.argv[3])}, "kernels": {}}
+out = {"meta": {"_about": sys.argv[4], "frames_per_launch": int(sys.argv[3]), "w": 1241, "h": 376}, "kernels": {}}
 for k in sorted(set(f) | set(w)):
     out["kernels"][k] = {"FETCH_SIZE_KB_avg_per_launch": round(f[k] / max(nf[k], 1), 1), "WRITE_SIZE_KB_avg_per_launch": round(w[k] / max(nw[k], 1), 1),
                          "launches": int(max(nf[k], nw[k]))}
