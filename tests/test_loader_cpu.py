@@ -31,3 +31,13 @@ def test_empty_and_bad_arguments():
     assert list(loader.FrameLoader([], chunk=4)) == []
     with pytest.raises(ValueError):
         loader.FrameLoader(["a"], chunk=1, overlap=1)
+
+
+def test_process_pool_decoding_matches_threads():
+    """processes=N: spawned worker processes decode into a shared-memory ring (threads stop scaling at the GIL)."""
+    paths = loader.load_image_paths(os.path.join(GOLDEN, "kitti02")) * 3       # 12 frames, 5 chunks of 3 with overlap 1
+    want = list(loader.FrameLoader(paths, chunk=3, overlap=1, workers=2))
+    got = list(loader.FrameLoader(paths, chunk=3, overlap=1, processes=2))
+    assert len(got) == len(want) == 6
+    for a, b in zip(want, got):
+        assert b.dtype == np.uint8 and np.array_equal(a, b)

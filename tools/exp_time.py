@@ -12,9 +12,15 @@ def child(so):
         _lib.SO_PATH = os.path.abspath(so)
     lib = _lib.load()
     n = 32
-    pairs = [synth.make_pair(seed=s) for s in range(8)]
-    K = pairs[0][2]
-    A = np.stack([pairs[i % 8][0] for i in range(n)]); B = np.stack([pairs[i % 8][1] for i in range(n)])
+    if os.environ.get("EXP_KITTI"):      # the bundled KITTI frames instead of the synthetic generator
+        from visual_slam_amd import loader
+        fr = [loader.decode_gray(p) for p in loader.load_image_paths(os.path.join(ROOT, "tests", "golden", "kitti02"))]
+        K = synth.K_KITTI02
+        A = np.stack([fr[i % 3] for i in range(n)]); B = np.stack([fr[i % 3 + 1] for i in range(n)])
+    else:
+        pairs = [synth.make_pair(seed=s) for s in range(8)]
+        K = pairs[0][2]
+        A = np.stack([pairs[i % 8][0] for i in range(n)]); B = np.stack([pairs[i % 8][1] for i in range(n)])
     dA, dB = torch.from_numpy(A).cuda(), torch.from_numpy(B).cuda()
     ctx = _lib.Context(max_w=A.shape[2], max_h=A.shape[1], chunk_pairs=n, max_pairs=n, nfeatures=3000)
     h, w = A.shape[1:]

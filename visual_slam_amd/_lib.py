@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "libvo_mi355.so")
+SO_PATH = os.environ.get("VO_MI355_LIB") or os.path.join(_HERE, "libvo_mi355.so")   # the env override is for A/B builds (tools/exp_build.sh)
 
 VO_OK, VO_ERR_INVALID, VO_ERR_HIP, VO_ERR_CAPACITY, VO_ERR_TOO_FEW, VO_ERR_NO_MODEL = 0, -1, -2, -3, -4, -5
 
