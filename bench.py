@@ -632,7 +632,7 @@ def main():
             "dtype": "u8/int32 detect+match, f64 pose", "data": "synthetic",
             "config": {"workload": ("configs[2]: batch of 4096 synthetic 1241x376 pairs (configs[1] generator, seed = pair index), 3000 ORB features, 8 levels" if not args.config4 else
                                     "configs[3] (diagnostic): synthetic 3840x2160 pairs, 20000 ORB features, 8 levels"),
-                       "global_pairs": G, "pairs_on_rank0": B, "distinct_pairs_on_rank0": nd, "chunk_pairs": min(args.chunk, B), "pose_batch_pairs": B if args.pose_batch <= 0 else min(args.pose_batch, B), "lanes_per_context": int(os.environ.get("VO_LANES", "4")), "streams_per_gpu": S,
+                       "global_pairs": G, "pairs_on_rank0": B, "distinct_pairs_on_rank0": nd, "chunk_pairs": min(args.chunk, B), "pose_batch_pairs": B if args.pose_batch <= 0 else min(args.pose_batch, B), "lanes_per_context": int(os.environ.get("VO_LANES", "6")), "streams_per_gpu": S,
                        "contexts_join_every_step": bool(args.join_steps), "parallelism": "pairs sharded contiguously over ranks, no data-path collective; all_gather of 152-byte records per step",
                        "pairs_ok": ok, "pairs_total": int(len(res)), "timed_region_s": round(dt, 3), "input_generation_s": round(t_gen, 1)},
             "roofline": roofline, "cpu_baseline": cpu, "h2d": h2d, "png_decode": png, "latency": latency, "kitti": kitti,

@@ -2,6 +2,8 @@
 // (declared in include/vo_mi355.h; each stands behind one cv2 call of
 // /root/reference/libs/vo_utils.py).  No CPU fallback: every entry point runs HIP kernels.
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
 #include <cstddef>
 #include <cstring>
 #include <functional>
@@ -555,6 +557,8 @@ static int run_batches(vo_ctx* c, int B, int cp, const double K[9], vo_pair_resu
     };
     struct Pending { int b0 = -1, Pb = 0, slot = 0; std::vector<hipEvent_t> ev; } pend;
     int nb = 0, nchunk = 0;
+    static const bool hosttime = getenv("VO_HOSTTIME") != nullptr;   // diagnostic: how long the host needs to enqueue a call
+    const auto ht0 = std::chrono::steady_clock::now();
     for (int b0 = 0; b0 < B; b0 += c->max_pairs, nb++) {
         const int Pb = std::min(c->max_pairs, B - b0);
         const int slot = nb & 1;
@@ -599,10 +603,16 @@ static int run_batches(vo_ctx* c, int B, int cp, const double K[9], vo_pair_resu
         }
         pend = cur;
     }
+    const auto ht1 = std::chrono::steady_clock::now();
     if (pend.b0 >= 0) {
         c->slot = pend.slot;
         rc = pose_stage(c, pend.Pb, K, out + pend.b0, pst, pend.ev);
         if (rc != VO_OK) return drain(rc);
+    }
+    if (hosttime) {
+        const auto ht2 = std::chrono::steady_clock::now();
+        fprintf(stderr, "[vo] %d pairs, %d chunks: enqueue %.3f ms, pose stage + wait %.3f ms\n", B, nchunk,
+                std::chrono::duration<double, std::milli>(ht1 - ht0).count(), std::chrono::duration<double, std::milli>(ht2 - ht1).count());
     }
     return VO_OK;
 }

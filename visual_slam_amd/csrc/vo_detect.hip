@@ -306,9 +306,6 @@ __device__ __forceinline__ int lanes_below(unsigned long long m) {
 }
 
 #define FQ_CAP 4096
-#ifndef FAST_3LEVEL
-#define FAST_3LEVEL 0
-#endif
 __global__ __launch_bounds__(256) void k_fast_tiles(const Geom* __restrict__ g, FrameSrc src, const uint8_t* __restrict__ pyr,
                                                     const TileDesc* __restrict__ tiles, uint32_t* __restrict__ tile_list,
                                                     uint8_t* __restrict__ seg_cnt, int nframes) {
@@ -318,10 +315,6 @@ __global__ __launch_bounds__(256) void k_fast_tiles(const Geom* __restrict__ g, 
     __shared__ int bmpre[64];            // exclusive prefix of the popcounts of bm
     __shared__ uint16_t queue[FQ_CAP];   // brighter-arc candidates from the front, darker-arc candidates from the back
     __shared__ int qcnt;                 // brighter count | darker count << 16
-#if FAST_3LEVEL
-    __shared__ uint16_t queue1[FQ_CAP];  // survivors of the two-pair test (stage 1a), same layout
-    __shared__ int qcnt1;
-#endif
     __shared__ uint16_t corner[64 * 32]; // positions with a score > 0
     __shared__ int ccnt;
     const VBlock vb = xcd_block(g->ntiles, 1, nframes);
@@ -338,9 +331,6 @@ __global__ __launch_bounds__(256) void k_fast_tiles(const Geom* __restrict__ g, 
     // 252 lanes cover 14 rows per pass
     const int xa = x0 - 4 - PXO;
     if (tid == 0) { qcnt = 0; ccnt = 0; }
-#if FAST_3LEVEL
-    if (tid == 1) qcnt1 = 0;
-#endif
     if (tid >= 192) bm[tid - 192] = 0;
     if (tid < 252) {
         const int r0 = tid / 18, k = tid - r0 * 18;
@@ -387,77 +377,6 @@ __global__ __launch_bounds__(256) void k_fast_tiles(const Geom* __restrict__ g, 
     // wavefronts; one LDS atomic per wavefront and iteration reserves the queue space.
     const int cmax = min(VO_TILE_W + 2, Lw - 3 - (x0 - 1));   // FAST is defined 3 px inside the level
     const int rmax = Lh - 3 - (y0 - 1);
-#if FAST_3LEVEL
-    // Stage 1a: the same necessary test on TWO of the four even pairs only (vertical k = 0/8, horizontal k = 4/12: 8
-    // instead of 12 LDS dwords and half the min/max per position).  It lets 1.6x as many positions through as the
-    // four-pair test, so its survivors (queue1) go through stage 1b -- the other two pairs, on dense wavefronts --
-    // before the arc scores: on real frames under 10 % of the positions ever see more than the two-pair test.
-#pragma unroll
-    for (int it = 0; it < 2; it++) {
-        const int run = tid + 256 * it;          // 16 runs per row
-        const int r = run >> 4, k4 = (run & 15) * 4;
-        const uint32_t* rowC = reinterpret_cast<const uint32_t*>(&px[(r + 3) * PXP + k4]);
-        const uint32_t* rowP3 = reinterpret_cast<const uint32_t*>(&px[(r + 6) * PXP + k4]);
-        const uint32_t* rowM3 = reinterpret_cast<const uint32_t*>(&px[(r + 0) * PXP + k4]);
-        const uint32_t C0 = rowC[0], C1 = rowC[1], C2 = rowC[2], C3 = rowC[3];
-        const uint32_t P31 = rowP3[1], P32 = rowP3[2], M31 = rowM3[1], M32 = rowM3[2];
-        *reinterpret_cast<uint32_t*>(&sc[r * SCP + k4]) = 0;
-#define PRETEST2(i, v, a0, a8, a4, a12)                                                                              \
-        const int mm##i = (int)min(max(a0, a8), max(a4, a12));                                                        \
-        const int xm##i = (int)max(min(a0, a8), min(a4, a12));                                                        \
-        const int th##i = (r < rmax && k4 + i < cmax) ? thr : 4096;                                                   \
-        const bool pb##i = mm##i > (int)(v) + th##i, pd##i = xm##i < (int)(v) - th##i;                                  \
-        const unsigned long long mb##i = __ballot(pb##i), md##i = __ballot(pd##i);
-        PRETEST2(0, BYTE(C1, 2), BYTE(P31, 2), BYTE(M31, 2), BYTE(C2, 1), BYTE(C0, 3))
-        PRETEST2(1, BYTE(C1, 3), BYTE(P31, 3), BYTE(M31, 3), BYTE(C2, 2), BYTE(C1, 0))
-        PRETEST2(2, BYTE(C2, 0), BYTE(P32, 0), BYTE(M32, 0), BYTE(C2, 3), BYTE(C1, 1))
-        PRETEST2(3, BYTE(C2, 1), BYTE(P32, 1), BYTE(M32, 1), BYTE(C3, 0), BYTE(C1, 2))
-#undef PRETEST2
-        const int nb0 = (int)__popcll(mb0), nb1 = (int)__popcll(mb1), nb2 = (int)__popcll(mb2), nb3 = (int)__popcll(mb3);
-        const int nd0 = (int)__popcll(md0), nd1 = (int)__popcll(md1), nd2 = (int)__popcll(md2), nd3 = (int)__popcll(md3);
-        const int add = (nb0 + nb1 + nb2 + nb3) | ((nd0 + nd1 + nd2 + nd3) << 16);
-        int base = 0;
-        if (lane == 0 && add) base = atomicAdd(&qcnt1, add);
-        base = __builtin_amdgcn_readfirstlane(base);
-        const int ob = base & 0xFFFF, od = FQ_CAP - 1 - (base >> 16);
-        const int pos = r * 64 + k4;
-        if (pb0) queue1[ob + lanes_below(mb0)] = (uint16_t)pos;
-        if (pb1) queue1[ob + nb0 + lanes_below(mb1)] = (uint16_t)(pos + 1);
-        if (pb2) queue1[ob + nb0 + nb1 + lanes_below(mb2)] = (uint16_t)(pos + 2);
-        if (pb3) queue1[ob + nb0 + nb1 + nb2 + lanes_below(mb3)] = (uint16_t)(pos + 3);
-        if (pd0) queue1[od - lanes_below(md0)] = (uint16_t)pos;
-        if (pd1) queue1[od - nd0 - lanes_below(md1)] = (uint16_t)(pos + 1);
-        if (pd2) queue1[od - nd0 - nd1 - lanes_below(md2)] = (uint16_t)(pos + 2);
-        if (pd3) queue1[od - nd0 - nd1 - nd2 - lanes_below(md3)] = (uint16_t)(pos + 3);
-    }
-    __syncthreads();
-    // Stage 1b: the diagonal pairs (k = 2/10, 6/14) at the survivors, polarity-uniform wavefronts -> queue
-    {
-        const int n1b = qcnt1 & 0xFFFF, n1d = qcnt1 >> 16;
-        const int n1b64 = (n1b + 63) & ~63;
-        for (int q = tid; q < n1b64 + n1d; q += 256) {
-            const bool bright = q < n1b64;
-            bool pass = false;
-            int i = 0;
-            if (!bright || q < n1b) {
-                i = bright ? queue1[q] : queue1[FQ_CAP - 1 - (q - n1b64)];
-                const uint8_t* p = &px[((i >> 6) + 3) * PXP + (i & 63) + 3 + PXO];
-                const int v = p[0], a2 = p[CIRC(2)], a10 = p[CIRC(10)], a6 = p[CIRC(6)], a14 = p[CIRC(14)];
-                pass = bright ? min(max(a2, a10), max(a6, a14)) > v + thr : max(min(a2, a10), min(a6, a14)) < v - thr;
-            }
-            const unsigned long long m = __ballot(pass);
-            if (m) {
-                int base = 0;
-                if (lane == 0) base = atomicAdd(&qcnt, bright ? (int)__popcll(m) : (int)__popcll(m) << 16);
-                base = __builtin_amdgcn_readfirstlane(base);
-                if (pass) {
-                    if (bright) queue[(base & 0xFFFF) + lanes_below(m)] = (uint16_t)i;
-                    else queue[FQ_CAP - 1 - (base >> 16) - lanes_below(m)] = (uint16_t)i;
-                }
-            }
-        }
-    }
-#else
 #pragma unroll
     for (int it = 0; it < 2; it++) {
         const int run = tid + 256 * it;          // 16 runs per row
@@ -500,7 +419,6 @@ __global__ __launch_bounds__(256) void k_fast_tiles(const Geom* __restrict__ g, 
         if (pd2) queue[od - nd0 - nd1 - lanes_below(md2)] = (uint16_t)(pos + 2);
         if (pd3) queue[od - nd0 - nd1 - nd2 - lanes_below(md3)] = (uint16_t)(pos + 3);
     }
-#endif
     __syncthreads();
     // Stage 2: arc extremes + cornerScore of the queued positions, both queues in one pass: the darker queue starts at
     // the next multiple of 64 after the brighter one, so every wavefront is polarity-uniform.  A position cannot have a
