@@ -274,6 +274,7 @@ def main():
     ap.add_argument("--streams", type=int, default=1,
                     help="contexts per GPU, each driven by one host thread.  One is enough since round 2: a context spreads its chunks over "
                          "up to 4 internal lanes (workspace + stream each) by itself; more contexts are a diagnostic")
+    ap.add_argument("--sync-calls", action="store_true", help="diagnostic: one synchronous vo_pairs_run_device call per pass instead of submit / wait")
     ap.add_argument("--join-steps", action="store_true", help="diagnostic: all contexts finish a step before any starts the next one")
     ap.add_argument("--ba", action="store_true",
                     help="extra diagnostic: time the BA residual/Jacobian pass of configs[4] (1000 poses x 200k points x 5 obs, points "
@@ -356,10 +357,21 @@ def main():
         return ctxs[i].pairs_run_device(dA.data_ptr() + b0 * fsz, dB.data_ptr() + b0 * fsz, b1 - b0, W_IMG, H_IMG, W_IMG, K)
 
     def ctx_passes(i, nsteps):
-        """Context i makes `nsteps` passes over its share as back-to-back calls: its host thread does not wait for the other
-        contexts between passes, so one context's latency-bound pose stage (end of a call) overlaps the detect/match chunks
-        of the others instead of all contexts reaching it together.  Returns the records pass by pass."""
-        return [run_part(i) for _ in range(nsteps)]
+        """Context i makes `nsteps` passes over its share.  Each pass is one asynchronous submission (vo_pairs_submit_device)
+        with at most two in flight: the pose stage of pass k (about 3 ms, latency bound) runs while detect + match of pass
+        k+1 are already executing, instead of ending every pass with an idle GPU -- what matters once a rank's share of a
+        step is small (strong scaling at 8 GPUs: 512 pairs per step).  All passes complete inside the caller's timed
+        region (the last wait).  Returns the records pass by pass."""
+        b0, b1 = bounds[i]
+        if args.sync_calls or args.pose_batch > 0 or nsteps < 1:     # a submission is one pose wave
+            return [run_part(i) for _ in range(nsteps)]
+        out = []
+        for k in range(nsteps):
+            ctxs[i].pairs_submit_device(dA.data_ptr() + b0 * fsz, dB.data_ptr() + b0 * fsz, b1 - b0, W_IMG, H_IMG, W_IMG, K)
+            if k >= 1:
+                out.append(ctxs[i].pairs_wait())
+        out.append(ctxs[i].pairs_wait())
+        return out
 
     def run_steps(nsteps):
         # this rank's shard of the job, split over S contexts/streams (ctypes calls release the GIL); then (N > 1) the only
@@ -633,7 +645,7 @@ def main():
             "config": {"workload": ("configs[2]: batch of 4096 synthetic 1241x376 pairs (configs[1] generator, seed = pair index), 3000 ORB features, 8 levels" if not args.config4 else
                                     "configs[3] (diagnostic): synthetic 3840x2160 pairs, 20000 ORB features, 8 levels"),
                        "global_pairs": G, "pairs_on_rank0": B, "distinct_pairs_on_rank0": nd, "chunk_pairs": min(args.chunk, B), "pose_batch_pairs": B if args.pose_batch <= 0 else min(args.pose_batch, B), "lanes_per_context": int(os.environ.get("VO_LANES", "6")), "streams_per_gpu": S,
-                       "contexts_join_every_step": bool(args.join_steps), "parallelism": "pairs sharded contiguously over ranks, no data-path collective; all_gather of 152-byte records per step",
+                       "contexts_join_every_step": bool(args.join_steps), "calls": "synchronous" if (args.sync_calls or args.pose_batch > 0) else "submit/wait, 2 in flight", "parallelism": "pairs sharded contiguously over ranks, no data-path collective; all_gather of 152-byte records per step",
                        "pairs_ok": ok, "pairs_total": int(len(res)), "timed_region_s": round(dt, 3), "input_generation_s": round(t_gen, 1)},
             "roofline": roofline, "cpu_baseline": cpu, "h2d": h2d, "png_decode": png, "latency": latency, "kitti": kitti,
             "sequence_mode": seq, "ba_pass": ba_out, "kernels": kernels,

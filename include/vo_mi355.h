@@ -139,6 +139,18 @@ int vo_pairs_run_device(vo_ctx* ctx, const uint8_t* imgsA_dev, const uint8_t* im
                         int w, int h, int stride, const double K[9], double ratio,
                         vo_pair_result* out_host, void* stream);
 
+/* The same call in two halves, for callers that make it repeatedly on batches of at most max_pairs pairs (a rank's share
+ * of every step of a sharded job): vo_pairs_submit_device returns as soon as the work is enqueued, vo_pairs_wait blocks
+ * until the OLDEST submission in flight is complete and fills the out_host it was submitted with.  Up to two submissions
+ * may be in flight: the pose stage of one (latency bound, about 3 ms whatever the batch) then overlaps detect + match of
+ * the next instead of ending every call with an idle GPU.  The images must stay valid until the matching wait.  Results
+ * are those of vo_pairs_run_device.  vo_pairs_triangulate / vo_debug_read after a wait refer to the waited submission
+ * (the pose-stage buffers E / mask belong to the latest submission). */
+int vo_pairs_submit_device(vo_ctx* ctx, const uint8_t* imgsA_dev, const uint8_t* imgsB_dev, int B,
+                           int w, int h, int stride, const double K[9], double ratio,
+                           vo_pair_result* out_host, void* stream);
+int vo_pairs_wait(vo_ctx* ctx);
+
 /* Same with host images (adds the H2D copy). */
 int vo_pairs_run(vo_ctx* ctx, const uint8_t* imgsA, const uint8_t* imgsB, int B,
                  int w, int h, int stride, const double K[9], double ratio, vo_pair_result* out);

@@ -99,3 +99,39 @@ def test_device_images_from_unsynchronised_torch_op(kitti02, K02):
         got = ctx.sequence_run_device(d.data_ptr(), F, w, h, w, K02)
         assert _records_equal(got, ref)
     ctx.close()
+
+
+def test_submit_wait_equals_synchronous_calls(kitti02, K02):
+    """vo_pairs_submit_device / vo_pairs_wait (two submissions in flight, host-free RANSAC schedule, pinned result staging)
+    give the records of vo_pairs_run_device, for different batches in flight at once and across several lanes."""
+    import torch
+    from visual_slam_amd import _lib, synth
+    A, B = synth.make_batch(range(900, 912), workers=1)
+    A = np.concatenate([A, np.stack(kitti02[:3])]); B = np.concatenate([B, np.stack(kitti02[1:])])
+    flat = np.full_like(A[0], 99)
+    A[5] = flat; B[5] = flat                                                # a failing pair inside a batch
+    dA, dB = torch.from_numpy(A).cuda(), torch.from_numpy(B).cuda()
+    n, h, w = A.shape
+    K = synth.K_KITTI02
+    ctx = _lib.Context(max_w=w, max_h=h, chunk_pairs=2, max_pairs=8)       # 4 lanes
+    fs = h * w
+    spans = [(0, 8), (8, 15), (3, 9), (14, 15), (0, 15 - 7)]
+    want = [ctx.pairs_run_device(dA.data_ptr() + a * fs, dB.data_ptr() + a * fs, b - a, w, h, w, K) for a, b in spans]
+    got = []
+    for k, (a, b) in enumerate(spans):
+        ctx.pairs_submit_device(dA.data_ptr() + a * fs, dB.data_ptr() + a * fs, b - a, w, h, w, K)
+        if k >= 1:
+            got.append(ctx.pairs_wait())
+    got.append(ctx.pairs_wait())
+    for x, y in zip(want, got):
+        assert len(x) == len(y) and _records_equal(x, y)
+    assert want[0]["status"][5] != 0 and (np.delete(want[0]["status"], 5) == 0).all()
+    with pytest.raises(_lib.VoError):
+        ctx.pairs_wait()                                                     # nothing in flight
+    ctx.pairs_submit_device(dA.data_ptr(), dB.data_ptr(), 4, w, h, w, K)
+    with pytest.raises(_lib.VoError):
+        ctx.pairs_run_device(dA.data_ptr(), dB.data_ptr(), 4, w, h, w, K)   # synchronous calls are refused while one is in flight
+    with pytest.raises(_lib.VoError):
+        ctx.pairs_submit_device(dA.data_ptr(), dB.data_ptr(), 9, w, h, w, K)   # more than max_pairs
+    assert _records_equal(ctx.pairs_wait(), want[0][:4])
+    ctx.close()

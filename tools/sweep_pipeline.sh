@@ -1,7 +1,7 @@
-# GPU box: lanes x chunk sweep of bench.py, two runs each (one context per GPU)
+# GPU box: per-rank batch sizes of a strong-scaling run (4096 / N pairs per step), synchronous calls vs submit / wait
 set -e
-for rep in 1 2; do for cfg in "4 32" "6 32" "8 32" "4 16" "8 16" "4 64" "6 64" "6 24"; do
+for cfg in "512 --sync-calls" "512" "1024 --sync-calls" "1024" "2048" "4096 --sync-calls" "4096"; do
   set -- $cfg
-  VO_LANES=$1 timeout -k 10 200 python bench.py --steps 10 --warmup 3 --no-cpu --no-extras --chunk $2 > gpurun_out/sw_l$1_c$2.json 2> gpurun_out/sw.err
-  python -c "import json,sys; d=json.load(open('gpurun_out/sw_l$1_c$2.json')); print('lanes',$1,'chunk',$2,d['value'],d['config']['pairs_ok'])"
-done; done
+  timeout -k 10 200 python bench.py --steps 20 --warmup 3 --no-cpu --no-extras --pairs $1 $2 > gpurun_out/sw_p$1$2.json 2> gpurun_out/sw.err
+  python -c "import json,sys; d=json.load(open('gpurun_out/sw_p$1$2.json')); print('pairs',$1,'$2',d['value'],d['ms_per_step'],d['config']['pairs_ok'])"
+done

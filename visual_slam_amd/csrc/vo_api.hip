@@ -194,6 +194,8 @@ static int ctx_init(vo_ctx* c) {
     if (rc != VO_OK) return rc;
     HIP_TRY(c, hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming));
     HIP_TRY(c, hipStreamCreateWithFlags(&c->pose_stream, hipStreamNonBlocking));
+    for (int i = 0; i < 2; i++) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_done[i], hipEventDisableTiming));
+    HIP_TRY(c, hipHostMalloc((void**)&c->h_result, 2 * (size_t)c->max_pairs * sizeof(vo_pair_result), hipHostMallocDefault));
     const long kc = c->kp_cap, MP = c->max_pairs;
     const long W = c->max_w, H = c->max_h;
     long tiles = 0, btiles = 0, rt = 0;
@@ -283,6 +285,8 @@ void vo_ctx_destroy(vo_ctx* c) {
     for (DevBuf* b : bufs) dev_free(*b);
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
     if (c->ev_in) (void)hipEventDestroy(c->ev_in);
+    for (int i = 0; i < 2; i++) if (c->ev_done[i]) (void)hipEventDestroy(c->ev_done[i]);
+    if (c->h_result) (void)hipHostFree(c->h_result);
     if (c->pose_stream) (void)hipStreamDestroy(c->pose_stream);
     delete c;
 }
@@ -541,6 +545,7 @@ struct Stager {
 
 static int run_batches(vo_ctx* c, int B, int cp, const double K[9], vo_pair_result* out, hipStream_t user,
                        const std::function<int(vo_ctx*, hipStream_t, int, int, int)>& chunk, const Stager* stg = nullptr) {
+    if (c->n_submitted != c->n_waited) return vo_fail(c, VO_ERR_INVALID, "a submission is in flight on this context: call vo_pairs_wait first");
     const bool serial = c->timing;
     const int nl = serial ? 1 : 1 + (int)c->lanes.size();
     auto lane = [&](int i) { return i == 0 ? c : c->lanes[i - 1]; };
@@ -634,6 +639,79 @@ int vo_pairs_run_device(vo_ctx* c, const uint8_t* imgsA, const uint8_t* imgsB, i
         if (r != VO_OK) return r;
         return vo_launch_match_impl(L, Pc, Pc, ratio, p0, nullptr, st);
     });
+}
+
+// ---- asynchronous form of vo_pairs_run_device: submit returns as soon as the work is enqueued, wait returns the records.
+// With two submissions in flight the pose stage of call k (pose stream; a host-free RANSAC schedule) overlaps detect +
+// match of call k+1 (lane streams): what a strong-scaling rank with a small per-step share needs (512 pairs per step:
+// 42.8 k pairs/s with the synchronous call, whose 3 ms pose tail nothing overlaps).
+int vo_pairs_submit_device(vo_ctx* c, const uint8_t* imgsA, const uint8_t* imgsB, int B, int w, int h, int stride, const double K[9], double ratio,
+                           vo_pair_result* out, void* stream) {
+    if (!c) return VO_ERR_INVALID;
+    if (!imgsA || !imgsB || !K || !out || B < 1 || stride < w) return vo_fail(c, VO_ERR_INVALID, "vo_pairs_submit_device: bad arguments");
+    if (B > c->max_pairs) return vo_fail(c, VO_ERR_INVALID, "vo_pairs_submit_device: more pairs than max_pairs (one pose wave per submission)");
+    if (c->timing) return vo_fail(c, VO_ERR_INVALID, "vo_pairs_submit_device: not available in the kernel-timing mode");
+    if (c->n_submitted - c->n_waited >= 2) return vo_fail(c, VO_ERR_INVALID, "vo_pairs_submit_device: two submissions are in flight, call vo_pairs_wait first");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (c->n_submitted != c->n_waited && c->geom_valid && (c->geom.w != w || c->geom.h != h))
+        return vo_fail(c, VO_ERR_INVALID, "vo_pairs_submit_device: the frame size cannot change while a submission is in flight");
+    int rc = vo_build_geometry(c, w, h);
+    if (rc != VO_OK) return rc;
+    propagate_geometry(c);
+    const int slot = (int)(c->n_submitted & 1);
+    const int nl = 1 + (int)c->lanes.size();
+    auto lane = [&](int i) { return i == 0 ? c : c->lanes[i - 1]; };
+    std::vector<hipStream_t> lst(nl);
+    for (int i = 0; i < nl; i++) lst[i] = lane(i)->stream;
+    rc = order_after(c, (hipStream_t)stream, lst);
+    if (rc != VO_OK) return rc;
+    const long fs = (long)stride * h;
+    unsigned used = 0;
+    int nchunk = 0;
+    for (int p0 = 0; p0 < B; p0 += c->chunk_pairs, nchunk++) {
+        const int Pc = std::min(c->chunk_pairs, B - p0);
+        const int li = (int)((c->n_submitted * 3 + nchunk) % nl);     // successive submissions start on different lanes
+        vo_ctx* L = lane(li);
+        L->slot = slot;
+        FrameSrc src{imgsA + (long)p0 * fs, imgsB + (long)p0 * fs, Pc, stride, fs};
+        L->last_src = src; L->last_frames = 2 * Pc;
+        rc = vo_launch_detect(L, src, 2 * Pc, lst[li]);
+        if (rc == VO_OK) rc = vo_launch_match_impl(L, Pc, Pc, ratio, p0, nullptr, lst[li]);
+        if (rc != VO_OK) return L != c ? vo_fail(c, rc, L->err) : rc;
+        c->last_lane = li;
+        used |= 1u << li;
+    }
+    hipStream_t pst = c->pose_stream;
+    for (int li = 0; li < nl; li++)
+        if (used >> li & 1) {
+            HIP_TRY(c, hipEventRecord(lane(li)->ev_lane[slot], lst[li]));
+            HIP_TRY(c, hipStreamWaitEvent(pst, lane(li)->ev_lane[slot], 0));
+        }
+    c->slot = slot;
+    rc = vo_launch_ransac(c, B, K, 0.999, 1.0, 1000, pst, true);
+    if (rc == VO_OK) rc = vo_launch_recover(c, B, K, 50.0, pst);
+    if (rc != VO_OK) return rc;
+    hipLaunchKernelGGL(k_results, dim3((B + 63) / 64), dim3(64), 0, pst, (const PoseWork*)c->d_pose.p, (const int*)c->nmatch(),
+                       (const int2*)c->pair_nkp(), B, (vo_pair_result*)c->d_result.p);
+    HIP_TRY(c, hipMemcpyAsync(c->h_result + (size_t)slot * c->max_pairs, c->d_result.p, (size_t)B * sizeof(vo_pair_result), hipMemcpyDeviceToHost, pst));
+    HIP_TRY(c, hipEventRecord(c->ev_done[slot], pst));
+    c->sub[slot].live = true; c->sub[slot].B = B; c->sub[slot].out = out;
+    c->n_submitted++;
+    return VO_OK;
+}
+
+// Waits for the OLDEST submission in flight and writes its records to the `out` it was submitted with.
+int vo_pairs_wait(vo_ctx* c) {
+    if (!c) return VO_ERR_INVALID;
+    if (c->n_submitted == c->n_waited) return vo_fail(c, VO_ERR_INVALID, "vo_pairs_wait: nothing in flight");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const int slot = (int)(c->n_waited & 1);
+    HIP_TRY(c, hipEventSynchronize(c->ev_done[slot]));
+    memcpy(c->sub[slot].out, c->h_result + (size_t)slot * c->max_pairs, (size_t)c->sub[slot].B * sizeof(vo_pair_result));
+    c->sub[slot].live = false;
+    c->n_waited++;
+    c->slot = slot; c->last_pairs = c->sub[slot].B;     // vo_debug_read / vo_pairs_triangulate see this submission's pair arrays
+    return VO_OK;
 }
 
 // A sequence of F frames: pair i is (frame i, frame i+1), as the loop of vo.py:48-190 visits them.

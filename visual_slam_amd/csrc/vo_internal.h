@@ -137,6 +137,12 @@ struct vo_ctx {
     vo_ctx* owner = nullptr;
     std::vector<vo_ctx*> lanes;
     int last_lane = 0;                              // lane of the last chunk (vo_debug_read)
+    // asynchronous submissions (vo_pairs_submit_device / vo_pairs_wait): at most two in flight, one per slot
+    struct Submission { bool live = false; int B = 0; vo_pair_result* out = nullptr; };
+    Submission sub[2];
+    unsigned long n_submitted = 0, n_waited = 0;
+    hipEvent_t ev_done[2] = {nullptr, nullptr};
+    vo_pair_result* h_result = nullptr;             // pinned, [2][max_pairs]: a D2H copy into pageable memory would block the submit
     hipEvent_t ev_lane[2] = {nullptr, nullptr};     // this lane's chunks of the batch in slot s have been enqueued
     int debug_stop = 0;    // 0: run everything; 1: stop after FAST emit; 2: stop after retainBest #1 + Harris
     void* h_pinned = nullptr;
@@ -178,7 +184,7 @@ int vo_noalloc_init(vo_ctx* c);      // resolves this device's copy of the no-al
 // pose.hip
 struct PoseK { double fx, fy, cx, cy; };
 // RANSAC (findEssentialMat) for pairs [0,P) of the pair arrays; E/mask/n_inlier left in d_pose / d_mask
-int vo_launch_ransac(vo_ctx* c, int P, const double K[9], double prob, double thr, int max_iters, hipStream_t st);
+int vo_launch_ransac(vo_ctx* c, int P, const double K[9], double prob, double thr, int max_iters, hipStream_t st, bool host_free = false);
 // recoverPose for pairs [0,P) using the E in d_pose (or E given per pair by the caller in d_pose)
 int vo_launch_recover(vo_ctx* c, int P, const double K[9], double dist_thresh, hipStream_t st);
 int vo_launch_triangulate_pairs(vo_ctx* c, int P, const double* dPm, const long* doffsets, float* dX3, float2* dq1, float2* dq2, hipStream_t st);

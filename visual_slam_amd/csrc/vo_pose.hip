@@ -614,7 +614,7 @@ __global__ void k_ransac_scan(PoseWork* pw, const int* __restrict__ nmatch, int 
         w.done = 1;
         if (maxGood <= 0) w.status = VO_ERR_NO_MODEL;
     } else {
-        atomicAdd(active, 1);
+        if (active) atomicAdd(active, 1);
     }
 }
 
@@ -791,7 +791,7 @@ static NormK make_normk(const double K[9]) {
     return nk;
 }
 
-int vo_launch_ransac(vo_ctx* c, int P, const double K[9], double prob, double thr, int max_iters, hipStream_t st) {
+int vo_launch_ransac(vo_ctx* c, int P, const double K[9], double prob, double thr, int max_iters, hipStream_t st, bool host_free) {
     if (P < 1 || P > c->max_pairs) return vo_fail(c, VO_ERR_INVALID, "pair count exceeds max_pairs");
     const int kp_cap = c->kp_cap;
     const NormK nk = make_normk(K);
@@ -814,12 +814,16 @@ int vo_launch_ransac(vo_ctx* c, int P, const double K[9], double prob, double th
     int iters_done = 0;
     for (int round = 0; iters_done < std::max(max_iters, 1); round++) {
         const int nh = round == 0 ? first_round : VO_HYP_ROUND;
-        HIP_TRY(c, hipMemsetAsync(active, 0, sizeof(int), st));
+        if (!host_free) HIP_TRY(c, hipMemsetAsync(active, 0, sizeof(int), st));
         hipLaunchKernelGGL(k_ransac_sample, dim3(pb), dim3(64), 0, st, pw, nmatch, P, nh, samples);
         hipLaunchKernelGGL(k_ransac_solve, dim3((P * nh + DK_T - 1) / DK_T), dim3(DK_T), 0, st, pw, nmatch, P, nh, kp_cap, q1, q2, nk, samples, models, nmodels);
         hipLaunchKernelGGL(k_ransac_score, dim3((nh + 3) / 4, P), dim3(256), 0, st, pw, nmatch, P, nh, kp_cap, q1, q2, nk, thr2, models, nmodels, counts);
-        hipLaunchKernelGGL(k_ransac_scan, dim3(pb), dim3(64), 0, st, pw, nmatch, P, nh, prob, models, nmodels, counts, active);
+        hipLaunchKernelGGL(k_ransac_scan, dim3(pb), dim3(64), 0, st, pw, nmatch, P, nh, prob, models, nmodels, counts, host_free ? nullptr : active);
         iters_done += nh;
+        // Host-free schedule (the asynchronous entry point): every round up to max_iters is enqueued; once a pair is done
+        // all its wavefronts exit at their first load, so the rounds nobody needs are a few empty launches on the pose
+        // stream.  Otherwise the host reads the number of pairs still active after every round and stops early.
+        if (host_free) continue;
         int h_active = 0;
         HIP_TRY(c, hipMemcpyAsync(&h_active, active, sizeof(int), hipMemcpyDeviceToHost, st));
         HIP_TRY(c, hipStreamSynchronize(st));
