@@ -306,6 +306,12 @@ __device__ __forceinline__ int lanes_below(unsigned long long m) {
 }
 
 #define FQ_CAP 4096
+#ifndef VO_SELECT_SMALL_CAP
+#define VO_SELECT_SMALL_CAP 3584
+#endif
+#ifndef VO_SELECT_BIG_LEVELS
+#define VO_SELECT_BIG_LEVELS 3   // levels whose first retainBest gets the 80 KB LDS variant
+#endif
 __global__ __launch_bounds__(256) void k_fast_tiles(const Geom* __restrict__ g, FrameSrc src, const uint8_t* __restrict__ pyr,
                                                     const TileDesc* __restrict__ tiles, uint32_t* __restrict__ tile_list,
                                                     uint8_t* __restrict__ seg_cnt, int nframes) {
@@ -858,12 +864,12 @@ __device__ int retain_best(float* key, PT* pay, QT* lpos, QT* rpos, int n, int n
 // workgroups fit a CU.  The payloads are gathered through the permutation at the end (staged in the stopper arrays).
 template <int NT, int CAP>
 __global__ __launch_bounds__(NT) void k_select(const Geom* __restrict__ g, float* key, uint32_t* pay, uint32_t* lpos, uint32_t* rpos,
-                                               const int* __restrict__ cnt_in, int* __restrict__ cnt_out, int mult) {
+                                               const int* __restrict__ cnt_in, int* __restrict__ cnt_out, int mult, int l0) {
     __shared__ int s_wl[NT / 64 < 4 ? 4 : NT / 64], s_wr[NT / 64], s_K, s_tabL[64], s_tabR[64];
     __shared__ float l_key[CAP];
     __shared__ uint16_t l_idx[CAP];
     __shared__ __attribute__((aligned(4))) uint16_t l_pos[2 * CAP];
-    const int l = blockIdx.x, f = blockIdx.y, tid = threadIdx.x;
+    const int l = l0 + blockIdx.x, f = blockIdx.y, tid = threadIdx.x;
     const LevelGeom& L = g->lv[l];
     const long base = (long)f * g->cand_frame + L.cand_ofs;
     key += base; pay += base; lpos += base; rpos += base;
@@ -1407,12 +1413,19 @@ int vo_launch_detect(vo_ctx* c, const FrameSrc& src, int F, hipStream_t st) {
     if (c->debug_stop == 1) { HIP_TRY(c, hipGetLastError()); return VO_OK; }
     // long candidate lists (4K frames: ~10^5 per level) are pass-bound, short ones barrier-bound
     if ((long)g.w * g.h > 2000000L)
-        KT(c, st, VO_K_SELECT1, hipLaunchKernelGGL((k_select<1024, 64>), dim3(g.nlevels, F), dim3(1024), 0, st, dg, key, payload, (uint32_t*)c->d_lpos.p, (uint32_t*)c->d_rpos.p, cnt_fast, cnt_sel1, 2));
-    else
-        KT(c, st, VO_K_SELECT1, hipLaunchKernelGGL((k_select<256, 8000>), dim3(g.nlevels, F), dim3(256), 0, st, dg, key, payload, (uint32_t*)c->d_lpos.p, (uint32_t*)c->d_rpos.p, cnt_fast, cnt_sel1, 2));
+        KT(c, st, VO_K_SELECT1, hipLaunchKernelGGL((k_select<1024, 64>), dim3(g.nlevels, F), dim3(1024), 0, st, dg, key, payload, (uint32_t*)c->d_lpos.p, (uint32_t*)c->d_rpos.p, cnt_fast, cnt_sel1, 2, 0));
+    else {
+        // The lists of the small levels are short (level l holds about 1.44^-l of level 0's candidates): they get a variant with
+        // 30 KB instead of 80 KB of LDS per workgroup, so that the LDS-tiled kernels of the other lanes (FAST, blur, rBRIEF,
+        // matcher) can share a CU with the replay instead of waiting for it.  A list longer than CAP runs from global memory.
+        const int split = std::min(VO_SELECT_BIG_LEVELS, g.nlevels);
+        KT(c, st, VO_K_SELECT1, hipLaunchKernelGGL((k_select<256, 8000>), dim3(split, F), dim3(256), 0, st, dg, key, payload, (uint32_t*)c->d_lpos.p, (uint32_t*)c->d_rpos.p, cnt_fast, cnt_sel1, 2, 0));
+        if (g.nlevels > split)
+            KT(c, st, VO_K_SELECT1, hipLaunchKernelGGL((k_select<256, VO_SELECT_SMALL_CAP>), dim3(g.nlevels - split, F), dim3(256), 0, st, dg, key, payload, (uint32_t*)c->d_lpos.p, (uint32_t*)c->d_rpos.p, cnt_fast, cnt_sel1, 2, split));
+    }
     KT(c, st, VO_K_HARRIS, hipLaunchKernelGGL(k_harris, dim3(pad8(HARRIS_BX * g.nlevels * F)), dim3(256), 0, st, dg, src, pyr, cnt_sel1, key, payload, F));
     if (c->debug_stop == 2) { HIP_TRY(c, hipGetLastError()); return VO_OK; }
-    KT(c, st, VO_K_SELECT2, hipLaunchKernelGGL((k_select<256, 2048>), dim3(g.nlevels, F), dim3(256), 0, st, dg, key, payload, (uint32_t*)c->d_lpos.p, (uint32_t*)c->d_rpos.p, cnt_sel1, cnt_sel2, 1));
+    KT(c, st, VO_K_SELECT2, hipLaunchKernelGGL((k_select<256, 2048>), dim3(g.nlevels, F), dim3(256), 0, st, dg, key, payload, (uint32_t*)c->d_lpos.p, (uint32_t*)c->d_rpos.p, cnt_sel1, cnt_sel2, 1, 0));
     KT(c, st, VO_K_ORIENT, hipLaunchKernelGGL(k_orient, dim3(pad8(ORIENT_BX * g.nlevels * F)), dim3(256), 0, st, dg, src, pyr, cnt_sel2, key, payload, (vo_keypoint*)c->d_kp.p,
                        (uint32_t*)c->d_kplvl.p, (int*)c->d_nkp.p, (int*)c->d_frame_status.p, F));
     if (fork_blur) HIP_TRY(c, hipStreamWaitEvent(st, c->ev_join, 0));
