@@ -494,7 +494,7 @@ def main():
                    "pairs_run_device_B1_ms": round(float(np.median(ts[5:])) * 1e3, 3),
                    "dropin_get_matches_ms": round(float(np.median(tg[2:])) * 1e3, 3), "dropin_get_pose_ms": round(float(np.median(tp[2:])) * 1e3, 3),
                    "dropin_total_ms": round(float(np.median(np.array(tg[2:]) + np.array(tp[2:]))) * 1e3, 3), "matches": nm,
-                   "note": "medians after warm-up; the drop-in path uploads both frames and reads keypoints, descriptors and matches back to host per call"}
+                   "note": "medians after warm-up; the drop-in path uploads both frames per call (vo_get_matches) and reads only q1 / q2 back; get_pose uploads them again"}
         c1.close()
 
         # ---- configs[0]: the bundled KITTI frames (tests/golden/kitti02, the reference's assets/test_imgs/02/000000-000003.png),

@@ -144,8 +144,9 @@ int vo_pairs_run_device(vo_ctx* ctx, const uint8_t* imgsA_dev, const uint8_t* im
  * until the OLDEST submission in flight is complete and fills the out_host it was submitted with.  Up to two submissions
  * may be in flight: the pose stage of one (latency bound, about 3 ms whatever the batch) then overlaps detect + match of
  * the next instead of ending every call with an idle GPU.  The images must stay valid until the matching wait.  Results
- * are those of vo_pairs_run_device.  vo_pairs_triangulate / vo_debug_read after a wait refer to the waited submission
- * (the pose-stage buffers E / mask belong to the latest submission). */
+ * are those of vo_pairs_run_device.  While a submission is in flight every other entry point of the context except
+ * submit / wait returns VO_ERR_INVALID (they share its buffers); after the last wait, vo_pairs_triangulate and
+ * vo_debug_read refer to the submission waited for last. */
 int vo_pairs_submit_device(vo_ctx* ctx, const uint8_t* imgsA_dev, const uint8_t* imgsB_dev, int B,
                            int w, int h, int stride, const double K[9], double ratio,
                            vo_pair_result* out_host, void* stream);

@@ -126,11 +126,17 @@ def test_submit_wait_equals_synchronous_calls(kitti02, K02):
     for x, y in zip(want, got):
         assert len(x) == len(y) and _records_equal(x, y)
     assert want[0]["status"][5] != 0 and (np.delete(want[0]["status"], 5) == 0).all()
+    # with nothing in flight any more, the pair arrays of the submission waited for last (pairs 0..7) serve vo_pairs_triangulate
+    P = np.tile((K @ np.eye(4)[:3])[None], (8, 1, 1))
+    X, q1, q2, off = ctx.pairs_triangulate(P, P)
+    assert np.array_equal(np.diff(off), np.where(got[-1]["status"] == 0, got[-1]["n_match"], 0)) and len(X) == off[-1]
     with pytest.raises(_lib.VoError):
         ctx.pairs_wait()                                                     # nothing in flight
     ctx.pairs_submit_device(dA.data_ptr(), dB.data_ptr(), 4, w, h, w, K)
     with pytest.raises(_lib.VoError):
         ctx.pairs_run_device(dA.data_ptr(), dB.data_ptr(), 4, w, h, w, K)   # synchronous calls are refused while one is in flight
+    with pytest.raises(_lib.VoError):
+        ctx.pairs_triangulate(P, P)                                          # and so is everything else that shares its buffers
     with pytest.raises(_lib.VoError):
         ctx.pairs_submit_device(dA.data_ptr(), dB.data_ptr(), 9, w, h, w, K)   # more than max_pairs
     assert _records_equal(ctx.pairs_wait(), want[0][:4])

@@ -313,6 +313,13 @@ int vo_get_kernel_timing(vo_ctx* c, float ms[VO_N_KERNELS], int32_t launches[VO_
     return VO_OK;
 }
 
+// The synchronous entry points reuse the buffers a submission in flight (vo_pairs_submit_device) is working on.
+#define REFUSE_IN_FLIGHT(c, name)                                                                                        \
+    do {                                                                                                                 \
+        if ((c)->n_submitted != (c)->n_waited)                                                                           \
+            return vo_fail((c), VO_ERR_INVALID, name ": a submission is in flight on this context, call vo_pairs_wait first"); \
+    } while (0)
+
 // -------------------------------------------------------------------- detectAndCompute
 // host frames -> tight device frames.  Contiguous rows (stride == w, the usual case) go as ONE linear copy: hipMemcpy2D from
 // pageable memory copies row by row (measured 0.13 GB/s for 1241-byte rows against ~20 GB/s for the linear copy).
@@ -324,6 +331,7 @@ static hipError_t copy_frames_h2d(void* dst, const uint8_t* src, int w, int stri
 int vo_orb_detect_compute(vo_ctx* c, const uint8_t* img, int w, int h, int stride, vo_keypoint* kps, uint8_t* desc, int cap, int* n) {
     if (!c) return VO_ERR_INVALID;
     if (!img || !n || w <= 0 || h <= 0 || stride < w) return vo_fail(c, VO_ERR_INVALID, "vo_orb_detect_compute: bad arguments");
+    REFUSE_IN_FLIGHT(c, "vo_orb_detect_compute");
     HIP_TRY(c, hipSetDevice(c->device));
     int rc = vo_build_geometry(c, w, h);
     if (rc != VO_OK) return rc;
@@ -355,6 +363,7 @@ static int match_host(vo_ctx* c, const uint8_t* q, int nq, const uint8_t* t, int
     HIP_TRY(c, hipSetDevice(c->device));
     hipStream_t st = c->stream;
     c->slot = 0;
+    REFUSE_IN_FLIGHT(c, "matcher");
     const long kc = c->kp_cap;
     int hn[2] = {nq, nt};
     HIP_TRY(c, hipMemcpyAsync(c->d_nkp.p, hn, 8, hipMemcpyHostToDevice, st));
@@ -407,6 +416,7 @@ int vo_match_knn2_ratio(vo_ctx* c, const uint8_t* q, int nq, const uint8_t* t, i
 // -------------------------------------------------------------------- pose
 static int upload_points(vo_ctx* c, const float* q1, const float* q2, int n, hipStream_t st) {
     if (n > c->kp_cap) return vo_fail(c, VO_ERR_CAPACITY, "more points than the context's keypoint capacity");
+    REFUSE_IN_FLIGHT(c, "pose entry point");
     int hn = n, zero = 0;
     c->slot = 0;
     HIP_TRY(c, hipMemcpyAsync(c->nmatch(), &hn, 4, hipMemcpyHostToDevice, st));
@@ -744,6 +754,7 @@ int vo_sequence_run_device(vo_ctx* c, const uint8_t* imgs, int F, int w, int h, 
 int vo_get_matches(vo_ctx* c, const uint8_t* imgA, const uint8_t* imgB, int w, int h, int stride, double ratio, float* q1, float* q2, int cap, int* n) {
     if (!c) return VO_ERR_INVALID;
     if (!imgA || !imgB || !n || w <= 0 || h <= 0 || stride < w || cap < 0) return vo_fail(c, VO_ERR_INVALID, "vo_get_matches: bad arguments");
+    REFUSE_IN_FLIGHT(c, "vo_get_matches");
     HIP_TRY(c, hipSetDevice(c->device));
     int rc = vo_build_geometry(c, w, h);
     if (rc != VO_OK) return rc;
@@ -782,6 +793,7 @@ int vo_pairs_triangulate(vo_ctx* c, int P, const double* P1, const double* P2, f
     if (!c) return VO_ERR_INVALID;
     if (!P1 || !P2 || !offsets || P < 0 || cap < 0) return vo_fail(c, VO_ERR_INVALID, "vo_pairs_triangulate: bad arguments");
     if (P > c->last_pairs) return vo_fail(c, VO_ERR_INVALID, "vo_pairs_triangulate: more pairs than the last pose wave held");
+    REFUSE_IN_FLIGHT(c, "vo_pairs_triangulate");
     offsets[0] = 0;
     if (P == 0) return VO_OK;
     HIP_TRY(c, hipSetDevice(c->device));
