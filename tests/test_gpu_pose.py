@@ -365,3 +365,33 @@ def test_batched_triangulation_sequence_and_pairs(oracle, kitti02, K02):
     X2, _, _, off2 = ctx.pairs_triangulate(P1[:3], P2[[0, 1, 1]])
     assert off2[1] == off2[2] and off2[3] - off2[2] == res["n_match"][2] and np.array_equal(X2[: off2[1]], X[: off[1]])
     ctx.close()
+
+
+def test_full_size_batch_is_a_permutation_of_its_pairs():
+    """BASELINE.json configs[2] at full size (4096 pairs, one context, six lanes, 128 chunks): the batch is 16 distinct
+    synthetic pairs in a random order, so every record must equal the record of its pair computed alone -- wherever in the
+    batch, on whichever lane and in whichever chunk it ran -- for the synchronous call and for submit / wait."""
+    import torch
+    from visual_slam_amd import _lib, synth
+    a, b = synth.make_batch(range(300, 316), workers=4)
+    n, h, w = a.shape
+    K = synth.K_KITTI02
+    small = _lib.Context(max_w=w, max_h=h, chunk_pairs=1, max_pairs=1)
+    alone = np.concatenate([small.pairs_run(a[i:i + 1], b[i:i + 1], K) for i in range(n)])
+    small.close()
+    assert (alone["status"] == 0).all()
+    rng = np.random.default_rng(11)
+    idx = rng.integers(0, n, 4096)
+    tA, tB = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
+    ti = torch.from_numpy(idx).cuda()
+    dA, dB = tA[ti].contiguous(), tB[ti].contiguous()
+    ctx = _lib.Context(max_w=w, max_h=h, chunk_pairs=32, max_pairs=4096)
+    sync = ctx.pairs_run_device(dA.data_ptr(), dB.data_ptr(), 4096, w, h, w, K)
+    ctx.pairs_submit_device(dA.data_ptr(), dB.data_ptr(), 4096, w, h, w, K)
+    ctx.pairs_submit_device(dA.data_ptr() + 1000 * h * w, dB.data_ptr() + 1000 * h * w, 3096, w, h, w, K)
+    first, second = ctx.pairs_wait(), ctx.pairs_wait()
+    ctx.close()
+    for f in alone.dtype.names:
+        assert np.array_equal(sync[f], alone[f][idx]), f
+        assert np.array_equal(first[f], alone[f][idx]), f
+        assert np.array_equal(second[f], alone[f][idx[1000:]]), f
