@@ -275,6 +275,9 @@ def main():
                     help="contexts per GPU, each driven by one host thread.  One is enough since round 2: a context spreads its chunks over "
                          "up to 4 internal lanes (workspace + stream each) by itself; more contexts are a diagnostic")
     ap.add_argument("--sync-calls", action="store_true", help="diagnostic: one synchronous vo_pairs_run_device call per pass instead of submit / wait")
+    ap.add_argument("--skip-mask", type=int, default=0,
+                    help="experiment builds only (-DVO_EXPERIMENT_SKIP): after the warm-up, leave out the kernels of this VO_K_* bit mask; "
+                         "the results are meaningless, the time tells what the kernel costs end to end")
     ap.add_argument("--join-steps", action="store_true", help="diagnostic: all contexts finish a step before any starts the next one")
     ap.add_argument("--ba", action="store_true",
                     help="extra diagnostic: time the BA residual/Jacobian pass of configs[4] (1000 poses x 200k points x 5 obs, points "
@@ -390,6 +393,8 @@ def main():
 
     res = run_steps(args.warmup) if args.warmup > 0 else None
     barrier()
+    if args.skip_mask:
+        os.environ["VO_SKIP_MASK"] = str(args.skip_mask)
     t0 = time.perf_counter()
     if args.join_steps:
         for _ in range(args.steps):

@@ -164,8 +164,17 @@ int vo_live_contexts(int device);   // contexts alive on the device (all threads
 void kt_begin(vo_ctx* c, hipStream_t st, int id);
 void kt_end(vo_ctx* c, hipStream_t st);
 int kt_collect(vo_ctx* c);   // after the stream is synchronised
+#ifdef VO_EXPERIMENT_SKIP
+// experiment builds only (tools/skip_sensitivity.sh): leave out the launches of the kernels named by the bit mask in the
+// environment, to measure what a kernel costs END TO END when everything overlaps (results are then meaningless)
+#include <cstdlib>
+static inline bool vo_skip(int id) { const char* e = getenv("VO_SKIP_MASK"); return e && ((atoi(e) >> id) & 1); }
+#define KT(c, st, id, launch) \
+    do { if (!vo_skip(id)) { kt_begin((c), (st), (id)); launch; kt_end((c), (st)); } } while (0)
+#else
 #define KT(c, st, id, launch) \
     do { kt_begin((c), (st), (id)); launch; kt_end((c), (st)); } while (0)
+#endif
 
 int vo_fail(vo_ctx* c, int code, const std::string& msg);
 #define HIP_TRY(c, expr)                                                                         \
