@@ -1,6 +1,7 @@
-# GPU box: A/B of library builds (build/exp/libvo_*.so) through bench.py, two rounds
+# GPU box: per-rank shares of a strong-scaling run x submissions in flight
 set -e
-for rep in 1 2; do for v in s8 s3 s4 s2; do
-  timeout -k 10 200 python bench.py --steps 20 --warmup 3 --no-cpu --no-extras --lib build/exp/libvo_$v.so > gpurun_out/sw_$v.json 2> gpurun_out/sw.err
-  python -c "import json,sys; d=json.load(open('gpurun_out/sw_$v.json')); print('$v',d['value'],d['config']['pairs_ok'], d['kernels']['k_select#1'])"
-done; done
+for cfg in "512 1" "512 2" "512 3" "1024 2" "1024 3" "4096 2" "4096 3"; do
+  set -- $cfg
+  timeout -k 10 200 python bench.py --steps 24 --warmup 3 --no-cpu --no-extras --pairs $1 --in-flight $2 > gpurun_out/sw_p$1_f$2.json 2> gpurun_out/sw.err
+  python -c "import json,sys; d=json.load(open('gpurun_out/sw_p$1_f$2.json')); print('pairs',$1,'in flight',$2,d['value'],d['ms_per_step'],d['config']['pairs_ok'])"
+done

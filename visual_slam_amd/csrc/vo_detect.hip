@@ -385,8 +385,11 @@ __global__ __launch_bounds__(256) void k_fast_tiles(const Geom* __restrict__ g, 
     const int rmax = Lh - 3 - (y0 - 1);
 #pragma unroll
     for (int it = 0; it < 2; it++) {
-        const int run = tid + 256 * it;          // 16 runs per row
-        const int r = run >> 4, k4 = (run & 15) * 4;
+        // 16 runs of 4 positions per row, 16 rows per iteration.  The two rows that share a half-wavefront (32 lanes = one LDS
+        // pass) are 4 apart: with the 20-dword row pitch their dwords fall into disjoint halves of the 32 banks
+        // (4 x 20 = 16 mod 32), where adjacent rows (offset 20) collide in 12 of 16 banks.
+        const int slot = tid >> 4;               // 0..15
+        const int r = 16 * it + ((slot >> 3) << 3) + ((slot & 1) << 2) + ((slot >> 1) & 3), k4 = (tid & 15) * 4;
         const uint32_t* rowC = reinterpret_cast<const uint32_t*>(&px[(r + 3) * PXP + k4]);
         const uint32_t* rowP2 = reinterpret_cast<const uint32_t*>(&px[(r + 5) * PXP + k4]);
         const uint32_t* rowM2 = reinterpret_cast<const uint32_t*>(&px[(r + 1) * PXP + k4]);
@@ -1298,6 +1301,8 @@ __global__ __launch_bounds__(256) void k_rbrief(const Geom* __restrict__ g, cons
     for (int j = 0; j < 4; j++) {
         const signed char* pp = &pat[(lane * 4 + j) * 4];
         px0[j] = (float)pp[0]; py0[j] = (float)pp[1]; px1[j] = (float)pp[2]; py1[j] = (float)pp[3];
+        // keep the 16 floats in registers: without the pin the compiler re-converts them from the packed bytes for every keypoint
+        asm volatile("" : "+v"(px0[j]), "+v"(py0[j]), "+v"(px1[j]), "+v"(py1[j]));
     }
     const uint8_t* fblur = blur + (long)f * g->blur_frame;
     uint8_t* mypatch = patch[wave];
@@ -1320,7 +1325,7 @@ __global__ __launch_bounds__(256) void k_rbrief(const Geom* __restrict__ g, cons
         const uint8_t* base = fblur + s_ofs[lvl] + (long)(UNPACK_Y(kl) - RB_R) * pitch + (x0 - ax);
 #pragma unroll
         for (int t = 0; t < RB_LOADS; t++)
-            if (l_src[t] >= 0) regs[t] = *reinterpret_cast<const uint32_t*>(base + (long)(l_src[t] >> 8) * pitch + 4 * (l_src[t] & 0xFF));
+            if (l_src[t] >= 0) regs[t] = *reinterpret_cast<const uint32_t*>(base + (__umul24((uint32_t)(l_src[t] >> 8), (uint32_t)pitch) + 4u * (uint32_t)(l_src[t] & 0xFF)));
     };
     const int nmine = (min(n - k0, RB_KPB) - wave + 3) >> 2;   // keypoints of this wavefront
     if (nmine > 0) fetch(0, cur_ax);
@@ -1342,7 +1347,8 @@ __global__ __launch_bounds__(256) void k_rbrief(const Geom* __restrict__ g, cons
             const float xa1 = px1[j] * a, yb1 = py1[j] * b, xb1 = px1[j] * b, ya1 = py1[j] * a;
             const int ix0 = __float2int_rn(xa0 - yb0), iy0 = __float2int_rn(xb0 + ya0);
             const int ix1 = __float2int_rn(xa1 - yb1), iy1 = __float2int_rn(xb1 + ya1);
-            const int t0 = center[iy0 * RB_PITCH + ix0], t1 = center[iy1 * RB_PITCH + ix1];
+            // |iy| <= 19: a 24-bit multiply (v_mul_i32_i24) instead of the quarter-rate 32-bit one
+            const int t0 = center[__mul24(iy0, RB_PITCH) + ix0], t1 = center[__mul24(iy1, RB_PITCH) + ix1];
             nib |= (uint32_t)(t0 < t1) << j;
         }
         const uint32_t hi = __shfl_down(nib, 1);
