@@ -96,3 +96,18 @@ def test_orb_pattern_table_hash():
     assert vals.shape == (1024,)
     assert vals[:4].tolist() == [8, -3, 9, 5] and vals[-4:].tolist() == [-1, -6, 0, -11]
     assert hashlib.sha256(vals.tobytes()).hexdigest() == quoted == "2164181aea6ff9ac426ca512d5130d15e1f6e3cd47b1cbdd568bbe1e55d49023"
+
+
+def test_bench_geometry_matches_the_survey_table():
+    """bench.py derives its algorithmic byte counts from the level geometry, not from constants."""
+    import bench
+    assert bench.level_sizes(1241, 376) == [(1241, 376), (1034, 313), (862, 261), (718, 218), (598, 181), (499, 151), (416, 126), (346, 105)]
+    assert bench.level_sizes(1226, 370)[1:] == [(1022, 308), (851, 257), (709, 214), (591, 178), (493, 149), (411, 124), (342, 103)]
+    assert bench.level_sizes(3840, 2160) == [(3840, 2160), (3200, 1800), (2667, 1500), (2222, 1250), (1852, 1042), (1543, 868), (1286, 723), (1072, 603)]
+    algo, P = bench.algo_bytes_per_frame(1241, 376, 3000)
+    assert P == 1444097 and algo["k_blur"] == 2888194 and algo["k_orient"] == 2247000 and algo["k_harris"] == 486000 and algo["k_rbrief"] == 1632000
+    assert bench.algo_bytes_per_frame(3840, 2160, 20000)[1] == 25677702
+    # PMC summaries taken at the KITTI size are not applied to another frame size
+    assert bench.measured_traffic("k_fast_tiles", 64, 3840, 2160) is None
+    t = bench.measured_traffic("k_fast_tiles", 64, 1241, 376)
+    assert t is None or 0.5 * 64 * P < t < 2.0 * 64 * P

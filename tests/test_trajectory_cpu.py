@@ -70,3 +70,34 @@ def test_sanitize_and_failure_mode():
     import pytest
     with pytest.raises(np.linalg.LinAlgError):
         tj.chain_poses([np.zeros((4, 4))])   # a failed pair is singular, as in the reference
+
+
+def test_projection_pairs_follow_the_reference_loop():
+    """P1 = K @ prev_pose[:3], P2 = K @ cur_pose[:3] with prev_pose = the chained pose before the pair (vo.py:65-67,92,176;
+    libs/vo_utils.py:153-157), for a chain that starts at identity and for one continued from a carried pose (second wave)."""
+    from visual_slam_amd import trajectory as tj
+    rng = np.random.default_rng(5)
+    K = np.array([[718.856, 0, 607.1928], [0, 718.856, 185.2157], [0, 0, 1.0]])
+    transfs = []
+    for _ in range(7):
+        w = rng.normal(0, 0.03, 3); th = np.linalg.norm(w); k = w / th
+        Kx = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+        T = np.eye(4); T[:3, :3] = np.eye(3) + np.sin(th) * Kx + (1 - np.cos(th)) * Kx @ Kx; T[:3, 3] = rng.normal(0, 1, 3)
+        transfs.append(T)
+    # the reference loop, literally
+    cur = prev = np.eye(4)
+    want = []
+    for T in transfs:
+        cur = cur @ np.linalg.inv(np.nan_to_num(T, neginf=0, posinf=0))
+        want.append((K @ prev[:3, :], K @ cur[:3, :]))
+        prev = cur
+    poses = tj.chain_poses(transfs)
+    P1, P2 = tj.projection_pairs(K, poses)
+    assert P1.shape == P2.shape == (7, 3, 4)
+    for i, (a, b) in enumerate(want):
+        assert np.array_equal(P1[i], a) and np.array_equal(P2[i], b)
+    # two waves: the second continues from the first wave's last pose
+    first = tj.chain_poses(transfs[:3])
+    second = tj.chain_poses(transfs[3:], start=first[-1])
+    Q1, Q2 = tj.projection_pairs(K, second, start=first[-1])
+    assert np.array_equal(Q1, P1[3:]) and np.array_equal(Q2, P2[3:])
