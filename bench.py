@@ -101,8 +101,8 @@ def valu_roofline(kernel, frames_per_launch, avg_launch_s, P, w, h):
     achieved = insts / avg_launch_s
     return {"wave_insts_per_launch": int(insts), "insts_per_px": round(insts * 64 / (P * frames_per_launch), 2),
             "achieved": round(achieved / 1e9, 2), "peak": round(VALU_PEAK_WAVE_INSTS / 1e9, 1), "unit": "G wave64-instructions/s",
-            "frac": round(achieved / VALU_PEAK_WAVE_INSTS, 4), "valu_busy": t["kernels"][kernel].get("valu_busy"),
-            "note": "peak = every SIMD issuing one full-rate wave64 VALU instruction per 2 cycles; v_min/v_max/v_cmp/v_perm and all VOP3 integer ops issue at half that rate (DESIGN.md 3.2), which is most of this kernel; valu_busy = fraction of SIMD-cycles with the VALU executing (SQ_ACTIVE_INST_VALU / (8 x SQ_BUSY_CYCLES))"}
+            "frac": round(achieved / VALU_PEAK_WAVE_INSTS, 4), "issue_frac_at_measured_clock": t["kernels"][kernel].get("valu_issue_frac"),
+            "note": "peak = every SIMD issuing one full-rate wave64 VALU instruction per 2 cycles (nominal 2.4 GHz); issue_frac_at_measured_clock = SQ_INSTS_VALU / (16 x SQ_BUSY_CYCLES) from the same PMC pass. 84 % of the hot stage's instructions (71 % of the kernel's, counted in the ISA) are half-rate (v_min/v_max SDWA, v_min3/v_max3, v_cmp, v_mbcnt), two issue slots each: 0.45 of the full-rate peak is about 0.8 of what this mix can issue (DESIGN.md 3.3)"}
 
 
 def cpu_model():
