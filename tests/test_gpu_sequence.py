@@ -141,3 +141,20 @@ def test_submit_wait_equals_synchronous_calls(kitti02, K02):
         ctx.pairs_submit_device(dA.data_ptr(), dB.data_ptr(), 9, w, h, w, K)   # more than max_pairs
     assert _records_equal(ctx.pairs_wait(), want[0][:4])
     ctx.close()
+
+
+def test_sequence_reprojection_errors_match_the_dropin():
+    """vo.py:107-109 for a whole sequence (batched triangulation + the BA residual pass) == the drop-in's per-frame
+    calc_reprojection_error on the same points."""
+    from visual_slam_amd import trajectory as tj
+    from visual_slam_amd.vo_utils import VisualOdometry
+    vo = VisualOdometry(os.path.join(GOLDEN, "kitti02"), False)
+    out = tj.run_sequence(vo, triangulate=True)
+    err, per_pair = tj.reprojection_errors(out, vo.K)
+    off = out["point_offsets"]
+    assert len(err) == off[-1] and len(per_pair) == 3
+    for i, pose in enumerate(out["poses"]):
+        a, b = int(off[i]), int(off[i + 1])
+        ref = vo.calc_reprojection_error(vo.K, vo.D, tj.rodrigues(pose[:3, :3]), pose[:3, 3], out["points"][a:b], out["q2"][a:b])
+        assert np.allclose(err[a:b], ref, rtol=1e-9, atol=1e-9)
+        assert abs(per_pair[i] - ref.mean()) <= 1e-9 * max(1.0, ref.mean())

@@ -188,3 +188,33 @@ def run_sequence(vo, max_frames=None, triangulate=False, wave=256, chunk=64):
         out["gt_path"] = g
         out["gt_error"] = gt_error(est[:len(g)], g)[0]
     return out
+
+
+def reprojection_errors(out, K, device=0):
+    """The reference's per-frame debug figure (vo.py:107-109) for a whole sequence in ONE launch:
+    `calc_reprojection_error(K, D=0, rvec_pose, tvec_pose, Q_local, q2)` of every triangulated point of every pair, with
+    (rvec_pose, tvec_pose) = (Rodrigues(cur_pose[:3,:3]), cur_pose[:3,3]) as vo.py:84-85 forms them (the chained pose is used
+    as is, like the reference does).  `out` is what `run_sequence(..., triangulate=True)` returns.  Evaluated by the BA
+    residual pass (`vo_ba_pass`): one observation per point, pose index = its pair.
+    Returns (per-point error float64 (M,), per-pair mean error float64 (N,), NaN for a pair without points)."""
+    from . import ba
+    poses, off = out["poses"], np.asarray(out["point_offsets"], np.int64)
+    n = len(poses)
+    M = int(off[-1])
+    per_pair = np.full(n, np.nan)
+    if M == 0:
+        return np.zeros(0), per_pair
+    pv = np.zeros((n, 6))
+    for i, p in enumerate(poses):
+        pv[i, :3] = rodrigues(p[:3, :3]).ravel()
+        pv[i, 3:] = p[:3, 3]
+    counts = np.diff(off)
+    obs_pose = np.repeat(np.arange(n, dtype=np.int32), counts)
+    plan = ba.BAPlan(obs_pose, np.arange(M, dtype=np.int32), n, M, device=device)
+    try:
+        err = plan.run(pv, np.asarray(out["points"], np.float64), np.asarray(out["q2"], np.float64), K)["norm"]
+    finally:
+        plan.close()
+    has = counts > 0
+    per_pair[has] = np.add.reduceat(err, off[:-1][has]) / counts[has]
+    return err, per_pair
