@@ -1113,20 +1113,29 @@ __global__ __launch_bounds__(256) void k_blur(const Geom* __restrict__ g, FrameS
 #pragma unroll
             for (int j = 0; j < BL_ROWS / 14; j++) q[14 * j * BL_SP / 4] = v[j];
         }
-    } else {
-        for (int i = tid; i < nrows * 18; i += 256) {
-            const int r = i / 18, k = i - r * 18;
-            const int y = reflect101c(y0 - 3 + r, L.h), x = x0 - 4 + 4 * k;
-            const uint8_t* rp = img + (long)y * pitch;
-            uint32_t v;
-            if (x >= 0 && x + 3 < L.w) {
-                __builtin_memcpy(&v, rp + x, 4);
-            } else {
-                v = 0;
+    } else if (tid < 252) {
+        // border tile (54 % of the tiles of a KITTI-size pyramid): the same lane mapping -- a lane owns one dword column and
+        // 5 rows, so the whole-dword test is per lane and only the rows are reflected; bytes are fetched one by one only
+        // where the dword itself crosses the level's left or right edge
+        const int r0 = tid / 18, k = tid - r0 * 18;
+        const int x = x0 - 4 + 4 * k;
+        const bool whole = x >= 0 && x + 3 < L.w;
+        int xb[4];
 #pragma unroll
-                for (int j = 0; j < 4; j++) v |= (uint32_t)rp[reflect101c(x + j, L.w)] << (8 * j);
+        for (int j = 0; j < 4; j++) xb[j] = reflect101c(x + j, L.w);
+#pragma unroll
+        for (int j = 0; j < BL_ROWS / 14; j++) {
+            const int r = r0 + 14 * j;
+            if (r < nrows) {
+                const uint8_t* rp = img + (long)reflect101c(y0 - 3 + r, L.h) * pitch;
+                uint32_t v;
+                if (whole) {
+                    __builtin_memcpy(&v, rp + x, 4);
+                } else {
+                    v = (uint32_t)rp[xb[0]] | ((uint32_t)rp[xb[1]] << 8) | ((uint32_t)rp[xb[2]] << 16) | ((uint32_t)rp[xb[3]] << 24);
+                }
+                *reinterpret_cast<uint32_t*>(&sp[r * BL_SP + 4 * k]) = v;
             }
-            *reinterpret_cast<uint32_t*>(&sp[r * BL_SP + 4 * k]) = v;
         }
     }
     __syncthreads();
