@@ -41,3 +41,18 @@ def test_process_pool_decoding_matches_threads():
     assert len(got) == len(want) == 6
     for a, b in zip(want, got):
         assert b.dtype == np.uint8 and np.array_equal(a, b)
+
+
+def test_packed_sequence_feeds_the_same_chunks(tmp_path):
+    """pack_sequence + FrameLoader(memory-mapped array): the decoded-once format yields the chunks the file list yields."""
+    paths = loader.load_image_paths(os.path.join(GOLDEN, "kitti02")) * 2
+    packed = loader.pack_sequence(paths, str(tmp_path / "seq.npy"))
+    arr = np.load(packed, mmap_mode="r")
+    assert arr.shape == (8, 376, 1241) and arr.dtype == np.uint8
+    want = list(loader.FrameLoader(paths, chunk=3, overlap=1, workers=2))
+    got = list(loader.FrameLoader(arr, chunk=3, overlap=1))
+    assert len(got) == len(want)
+    for a, b in zip(want, got):
+        assert np.array_equal(a, b)
+    with pytest.raises(ValueError):
+        loader.FrameLoader(np.zeros((2, 3)), chunk=2)
