@@ -578,11 +578,18 @@ def main():
                     c2.sequence_run_device(first.data_ptr(), first.shape[0], W_IMG, H_IMG, W_IMG, Kk)
                     t1 = time.perf_counter()
                     npairs = nok = 0
+                    held = []                                  # frames of the submissions in flight stay referenced until their wait
                     for fr in it:
-                        r = c2.sequence_run_device(fr.data_ptr(), fr.shape[0], W_IMG, H_IMG, W_IMG, Kk)
+                        c2.sequence_submit_device(fr.data_ptr(), fr.shape[0], W_IMG, H_IMG, W_IMG, Kk)
+                        held.append(fr)
+                        if len(held) == 2:
+                            r = c2.pairs_wait(); held.pop(0)
+                            npairs += len(r); nok += int((r["status"] == 0).sum())
+                    while held:
+                        r = c2.pairs_wait(); held.pop(0)
                         npairs += len(r); nok += int((r["status"] == 0).sum())
                     png["end_to_end_packed_to_pose"] = {"frame_pairs_per_sec": round(npairs / (time.perf_counter() - t1), 1), "pairs": npairs, "pairs_ok": nok,
-                                                        "note": "decoded frames (loader.pack_sequence format) -> pinned ring (8 copy threads) -> HBM -> vo_sequence_run_device in waves of 512 pairs, synchronous calls from one host thread"}
+                                                        "note": "decoded frames (loader.pack_sequence format) -> pinned ring (8 copy threads) -> HBM -> vo_sequence_submit_device / vo_pairs_wait in waves of 512 pairs, two in flight, one host thread"}
                     del arr, it
                 c2.close()
             except OSError:
@@ -604,9 +611,15 @@ def main():
 
         def seq_part(i, nsteps):
             r = None
-            for _ in range(nsteps):
-                r = ctxs[i].sequence_run_device(seqs[i].data_ptr(), seqs[i].shape[0], W_IMG, H_IMG, W_IMG, K)
-            return r
+            if args.sync_calls or args.pose_batch > 0:
+                for _ in range(nsteps):
+                    r = ctxs[i].sequence_run_device(seqs[i].data_ptr(), seqs[i].shape[0], W_IMG, H_IMG, W_IMG, K)
+                return r
+            for k in range(nsteps):                       # submit / wait, two passes in flight
+                ctxs[i].sequence_submit_device(seqs[i].data_ptr(), seqs[i].shape[0], W_IMG, H_IMG, W_IMG, K)
+                if k >= 1:
+                    r = ctxs[i].pairs_wait()
+            return ctxs[i].pairs_wait()
 
         def seq_run(nsteps):
             parts = list(pool.map(lambda i: seq_part(i, nsteps), range(S))) if pool else [seq_part(0, nsteps)]

@@ -151,6 +151,9 @@ int vo_pairs_submit_device(vo_ctx* ctx, const uint8_t* imgsA_dev, const uint8_t*
                            int w, int h, int stride, const double K[9], double ratio,
                            vo_pair_result* out_host, void* stream);
 int vo_pairs_wait(vo_ctx* ctx);
+/* vo_sequence_run_device in the same two halves (F - 1 <= max_pairs pairs per submission); vo_pairs_wait completes it. */
+int vo_sequence_submit_device(vo_ctx* ctx, const uint8_t* imgs_dev, int F, int w, int h, int stride,
+                              const double K[9], double ratio, vo_pair_result* out_host, void* stream);
 
 /* Same with host images (adds the H2D copy). */
 int vo_pairs_run(vo_ctx* ctx, const uint8_t* imgsA, const uint8_t* imgsB, int B,

@@ -132,6 +132,11 @@ def test_submit_wait_equals_synchronous_calls(kitti02, K02):
     assert np.array_equal(np.diff(off), np.where(got[-1]["status"] == 0, got[-1]["n_match"], 0)) and len(X) == off[-1]
     with pytest.raises(_lib.VoError):
         ctx.pairs_wait()                                                     # nothing in flight
+    # the sequence form: frames 0..8 of A taken as consecutive frames, two submissions in flight
+    seq_want = [ctx.sequence_run_device(dA.data_ptr() + a * fs, b - a, w, h, w, K) for a, b in ((0, 9), (4, 7))]
+    ctx.sequence_submit_device(dA.data_ptr(), 9, w, h, w, K)
+    ctx.sequence_submit_device(dA.data_ptr() + 4 * fs, 3, w, h, w, K)
+    assert _records_equal(ctx.pairs_wait(), seq_want[0]) and _records_equal(ctx.pairs_wait(), seq_want[1])
     ctx.pairs_submit_device(dA.data_ptr(), dB.data_ptr(), 4, w, h, w, K)
     with pytest.raises(_lib.VoError):
         ctx.pairs_run_device(dA.data_ptr(), dB.data_ptr(), 4, w, h, w, K)   # synchronous calls are refused while one is in flight

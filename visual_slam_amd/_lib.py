@@ -36,7 +36,7 @@ PAIR_DTYPE = np.dtype([("T", "<f8", (4, 4)), ("n_kp1", "<i4"), ("n_kp2", "<i4"),
 EXPORTS = [
     "vo_default_orb_params", "vo_ctx_create", "vo_ctx_destroy", "vo_last_error", "vo_orb_detect_compute", "vo_match_knn2_ratio",
     "vo_match_knn2", "vo_find_essential_ransac", "vo_recover_pose", "vo_triangulate", "vo_pairs_run_device", "vo_pairs_run", "vo_sequence_run_device", "vo_sequence_run", "vo_ba_plan_create", "vo_ba_plan_destroy", "vo_ba_pass_device", "vo_ba_pass",
-    "vo_match_knn2_ratio_noalloc", "vo_get_matches", "vo_pairs_triangulate", "vo_pairs_submit_device", "vo_pairs_wait", "vo_debug_read", "vo_set_debug_stop", "vo_set_kernel_timing", "vo_get_kernel_timing",
+    "vo_match_knn2_ratio_noalloc", "vo_get_matches", "vo_pairs_triangulate", "vo_pairs_submit_device", "vo_sequence_submit_device", "vo_pairs_wait", "vo_debug_read", "vo_set_debug_stop", "vo_set_kernel_timing", "vo_get_kernel_timing",
 ]
 
 _lib = None
@@ -76,6 +76,7 @@ def load():
     lib.vo_pairs_run_device.argtypes = [vp, vp, vp, i, i, i, i, vp, d, vp, vp]
     lib.vo_pairs_submit_device.argtypes = [vp, vp, vp, i, i, i, i, vp, d, vp, vp]
     lib.vo_pairs_wait.argtypes = [vp]
+    lib.vo_sequence_submit_device.argtypes = [vp, vp, i, i, i, i, vp, d, vp, vp]
     lib.vo_pairs_run.argtypes = [vp, vp, vp, i, i, i, i, vp, d, vp]
     lib.vo_sequence_run_device.argtypes = [vp, vp, i, i, i, i, vp, d, vp, vp]
     lib.vo_sequence_run.argtypes = [vp, vp, i, i, i, i, vp, d, vp]
@@ -252,6 +253,14 @@ class Context:
         out = np.zeros(B, PAIR_DTYPE)
         self._check(self.lib.vo_pairs_submit_device(self.h, C.c_void_p(ptrA), C.c_void_p(ptrB), B, w, h, stride, _ptr(K), float(ratio), _ptr(out),
                                                     C.c_void_p(stream) if stream else None))
+        self._inflight.append(out)
+
+    def sequence_submit_device(self, ptr, F, w, h, stride, K, ratio=0.45, stream=None):
+        """Asynchronous sequence_run_device (F - 1 <= max_pairs); pairs_wait() returns its records."""
+        K = np.ascontiguousarray(K, np.float64)
+        out = np.zeros(max(F - 1, 0), PAIR_DTYPE)
+        self._check(self.lib.vo_sequence_submit_device(self.h, C.c_void_p(ptr), F, w, h, stride, _ptr(K), float(ratio), _ptr(out),
+                                                       C.c_void_p(stream) if stream else None))
         self._inflight.append(out)
 
     def pairs_wait(self):

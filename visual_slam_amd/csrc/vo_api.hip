@@ -655,16 +655,14 @@ int vo_pairs_run_device(vo_ctx* c, const uint8_t* imgsA, const uint8_t* imgsB, i
 // With two submissions in flight the pose stage of call k (pose stream; a host-free RANSAC schedule) overlaps detect +
 // match of call k+1 (lane streams): what a strong-scaling rank with a small per-step share needs (512 pairs per step:
 // 42.8 k pairs/s with the synchronous call, whose 3 ms pose tail nothing overlaps).
-int vo_pairs_submit_device(vo_ctx* c, const uint8_t* imgsA, const uint8_t* imgsB, int B, int w, int h, int stride, const double K[9], double ratio,
-                           vo_pair_result* out, void* stream) {
-    if (!c) return VO_ERR_INVALID;
-    if (!imgsA || !imgsB || !K || !out || B < 1 || stride < w) return vo_fail(c, VO_ERR_INVALID, "vo_pairs_submit_device: bad arguments");
-    if (B > c->max_pairs) return vo_fail(c, VO_ERR_INVALID, "vo_pairs_submit_device: more pairs than max_pairs (one pose wave per submission)");
-    if (c->timing) return vo_fail(c, VO_ERR_INVALID, "vo_pairs_submit_device: not available in the kernel-timing mode");
-    if (c->n_submitted - c->n_waited >= 2) return vo_fail(c, VO_ERR_INVALID, "vo_pairs_submit_device: two submissions are in flight, call vo_pairs_wait first");
+static int submit_impl(vo_ctx* c, const char* name, int B, int cp, int w, int h, const double K[9], vo_pair_result* out, hipStream_t user,
+                       const std::function<int(vo_ctx*, hipStream_t, int, int)>& chunk) {
+    if (B > c->max_pairs) return vo_fail(c, VO_ERR_INVALID, std::string(name) + ": more pairs than max_pairs (one pose wave per submission)");
+    if (c->timing) return vo_fail(c, VO_ERR_INVALID, std::string(name) + ": not available in the kernel-timing mode");
+    if (c->n_submitted - c->n_waited >= 2) return vo_fail(c, VO_ERR_INVALID, std::string(name) + ": two submissions are in flight, call vo_pairs_wait first");
     HIP_TRY(c, hipSetDevice(c->device));
     if (c->n_submitted != c->n_waited && c->geom_valid && (c->geom.w != w || c->geom.h != h))
-        return vo_fail(c, VO_ERR_INVALID, "vo_pairs_submit_device: the frame size cannot change while a submission is in flight");
+        return vo_fail(c, VO_ERR_INVALID, std::string(name) + ": the frame size cannot change while a submission is in flight");
     int rc = vo_build_geometry(c, w, h);
     if (rc != VO_OK) return rc;
     propagate_geometry(c);
@@ -673,20 +671,15 @@ int vo_pairs_submit_device(vo_ctx* c, const uint8_t* imgsA, const uint8_t* imgsB
     auto lane = [&](int i) { return i == 0 ? c : c->lanes[i - 1]; };
     std::vector<hipStream_t> lst(nl);
     for (int i = 0; i < nl; i++) lst[i] = lane(i)->stream;
-    rc = order_after(c, (hipStream_t)stream, lst);
+    rc = order_after(c, user, lst);
     if (rc != VO_OK) return rc;
-    const long fs = (long)stride * h;
     unsigned used = 0;
     int nchunk = 0;
-    for (int p0 = 0; p0 < B; p0 += c->chunk_pairs, nchunk++) {
-        const int Pc = std::min(c->chunk_pairs, B - p0);
+    for (int p0 = 0; p0 < B; p0 += cp, nchunk++) {
         const int li = (int)((c->n_submitted * 3 + nchunk) % nl);     // successive submissions start on different lanes
         vo_ctx* L = lane(li);
         L->slot = slot;
-        FrameSrc src{imgsA + (long)p0 * fs, imgsB + (long)p0 * fs, Pc, stride, fs};
-        L->last_src = src; L->last_frames = 2 * Pc;
-        rc = vo_launch_detect(L, src, 2 * Pc, lst[li]);
-        if (rc == VO_OK) rc = vo_launch_match_impl(L, Pc, Pc, ratio, p0, nullptr, lst[li]);
+        rc = chunk(L, lst[li], p0, std::min(cp, B - p0));
         if (rc != VO_OK) return L != c ? vo_fail(c, rc, L->err) : rc;
         c->last_lane = li;
         used |= 1u << li;
@@ -708,6 +701,37 @@ int vo_pairs_submit_device(vo_ctx* c, const uint8_t* imgsA, const uint8_t* imgsB
     c->sub[slot].live = true; c->sub[slot].B = B; c->sub[slot].out = out;
     c->n_submitted++;
     return VO_OK;
+}
+
+int vo_pairs_submit_device(vo_ctx* c, const uint8_t* imgsA, const uint8_t* imgsB, int B, int w, int h, int stride, const double K[9], double ratio,
+                           vo_pair_result* out, void* stream) {
+    if (!c) return VO_ERR_INVALID;
+    if (!imgsA || !imgsB || !K || !out || B < 1 || stride < w) return vo_fail(c, VO_ERR_INVALID, "vo_pairs_submit_device: bad arguments");
+    const long fs = (long)stride * h;
+    return submit_impl(c, "vo_pairs_submit_device", B, c->chunk_pairs, w, h, K, out, (hipStream_t)stream, [&](vo_ctx* L, hipStream_t st, int p0, int Pc) {
+        FrameSrc src{imgsA + (long)p0 * fs, imgsB + (long)p0 * fs, Pc, stride, fs};
+        L->last_src = src; L->last_frames = 2 * Pc;
+        int r = vo_launch_detect(L, src, 2 * Pc, st);
+        if (r != VO_OK) return r;
+        return vo_launch_match_impl(L, Pc, Pc, ratio, p0, nullptr, st);
+    });
+}
+
+// the same for a sequence of F frames (F - 1 <= max_pairs consecutive pairs, each frame extracted once per chunk)
+int vo_sequence_submit_device(vo_ctx* c, const uint8_t* imgs, int F, int w, int h, int stride, const double K[9], double ratio,
+                              vo_pair_result* out, void* stream) {
+    if (!c) return VO_ERR_INVALID;
+    if (!imgs || !K || !out || F < 2 || stride < w) return vo_fail(c, VO_ERR_INVALID, "vo_sequence_submit_device: bad arguments");
+    const long fs = (long)stride * h;
+    const int cp = std::min(c->chunk_pairs, 2 * c->chunk_pairs - 1);
+    return submit_impl(c, "vo_sequence_submit_device", F - 1, cp, w, h, K, out, (hipStream_t)stream, [&](vo_ctx* L, hipStream_t st, int p0, int Pc) {
+        const uint8_t* first = imgs + (long)p0 * fs;
+        FrameSrc src{first, first, Pc + 1, stride, fs};
+        L->last_src = src; L->last_frames = Pc + 1;
+        int r = vo_launch_detect(L, src, Pc + 1, st);
+        if (r != VO_OK) return r;
+        return vo_launch_match_impl(L, Pc, 1, ratio, p0, nullptr, st);
+    });
 }
 
 // Waits for the OLDEST submission in flight and writes its records to the `out` it was submitted with.
