@@ -446,7 +446,7 @@ def main():
                                    "equiv_xor_popcount_Tlaneops": round(float(nk.sum()) * 16.0 / (kernels["k_match"]["ms_total"] * 1e-3) / 1e12, 2),
                                    "valu_xor_popcount_ceiling_Tlaneops": 36.1}
 
-    extras = rank == 0 and not args.no_extras and not args.config4
+    extras = rank == 0 and world == 1 and not args.no_extras and not args.config4      # the side legs are measured at N = 1 only
     h2d = latency = kitti = png = None
     if extras:
         # ---- H2D copy, reported separately (never part of `value`): pinned host memory -> HBM, and the library's host-image
@@ -668,7 +668,7 @@ def main():
         plan.close()
 
     cpu = None
-    if rank == 0 and not args.no_cpu:
+    if rank == 0 and world == 1 and not args.no_cpu:      # on rank 0 at N = 1 only
         cpu = cpu_baseline(imgsA, imgsB, K, NFEAT)
 
     if rank == 0:
