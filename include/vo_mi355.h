@@ -219,6 +219,13 @@ int vo_ba_pass(vo_ba_plan* plan, const double* poses, const double* points, cons
 #define VO_DBG_MATCHES 8        /* pair -> int32 [n][4] queryIdx, trainIdx, d1, d2 after ratio */
 #define VO_DBG_E_MASK 9         /* pair -> double E[9] followed by uint8 mask[n_match] */
 long vo_debug_read(vo_ctx* ctx, int what, int index, int level, void* out, long bytes);
+/* Parity hook for the five-point minimal solver of vo_find_essential_ransac (no counterpart in the reference's call
+ * surface: cv::findEssentialMat runs it internally, modules/calib3d/src/five-point.cpp EMEstimatorCallback::runKernel
+ * and cv::solvePoly in OpenCV 4.x).  Host pointers, n independent cases, one GPU lane each.
+ *   mode 0: in = n x 11 polynomial coefficients (ascending powers); out = n x 10 roots as (re, im) pairs
+ *   mode 1: in = n x (x1[5][2], x2[5][2]) normalised correspondences; out = n x 91: the model count, then up to ten
+ *           row-major 3x3 essential matrices (unused slots 0) */
+int vo_debug_minimal_solver(vo_ctx* ctx, int mode, const double* in, int n, double* out);
 /* retainBest permutes its list in place, so the FAST and SEL1 lists only exist if the detect
  * chain is stopped early: 0 = run everything (default), 1 = stop after the FAST lists,
  * 2 = stop after retainBest #1 + Harris. */

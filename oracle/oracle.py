@@ -177,6 +177,14 @@ def five_point(x1, x2):
     return Eb[:n].copy()
 
 
+def solve_poly10(coeffs):
+    """cv::solvePoly(coeffs, roots, 300) for one degree-10 coefficient vector (ascending powers) -> complex128 [10]"""
+    c = np.ascontiguousarray(coeffs, np.float64).reshape(11)
+    out = np.zeros(20)
+    lib().orc_solve_poly10(_ptr(c), _ptr(out))
+    return out.view(np.complex128).copy()
+
+
 def recover_pose(E, q1, q2, K, dist_thresh=50.0):
     q1 = np.ascontiguousarray(q1, np.float32).reshape(-1, 2); q2 = np.ascontiguousarray(q2, np.float32).reshape(-1, 2)
     E = np.ascontiguousarray(E, np.float64); K = np.ascontiguousarray(K, np.float64)

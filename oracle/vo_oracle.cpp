@@ -978,6 +978,12 @@ int orc_ratio_filter(const int32_t* d1, const int32_t* d2, int nq, double ratio,
 }
 
 int orc_five_point(const double* x1, const double* x2, double* Ebuf) { return five_point(x1, x2, Ebuf); }
+int orc_solve_poly10(const double* coeffs, double* roots_re_im) {
+    Cx r[16];
+    solve_poly(coeffs, 10, r);
+    for (int i = 0; i < 10; i++) { roots_re_im[2 * i] = r[i].re; roots_re_im[2 * i + 1] = r[i].im; }
+    return 10;
+}
 
 /* libs/vo_utils.py:141 -> findEssentialMat -> RANSACPointSetRegistrator::run (A.3) */
 int orc_find_essential_ransac(const float* q1, const float* q2, int n, const double K[9], double prob, double thr, int max_iters,

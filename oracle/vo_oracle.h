@@ -94,6 +94,8 @@ int orc_find_essential_ransac(const float* q1, const float* q2, int n, const dou
 
 /* five-point minimal solver on already-normalised points (x,y pairs).  Ebuf [10*9]. */
 int orc_five_point(const double* x1, const double* x2, double* Ebuf);
+/* cv::solvePoly on a degree-10 coefficient vector (ascending powers); roots as (re, im) pairs */
+int orc_solve_poly10(const double* coeffs, double* roots_re_im);
 
 /* cv::recoverPose(E, q1, q2, K, R, t) -- no input mask, distanceThresh given. */
 int orc_recover_pose(const double E[9], const float* q1, const float* q2, int n, const double K[9],

@@ -1,0 +1,86 @@
+"""The five-point minimal solver on the GPU (vo_debug_minimal_solver) against the CPU oracle, bit for bit: the
+Durand-Kerner root finder alone (cv::solvePoly, 300 sweeps) and the whole solver (null space, elimination, roots,
+back-substitution).  RANSAC's results are covered by test_gpu_pose.py; these cases reach the solver directly,
+including inputs RANSAC rarely draws (coincident and collinear points, reduced degree, overflow)."""
+import numpy as np
+import pytest
+
+from test_oracle_pose import two_view
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from visual_slam_amd import _lib
+    c = _lib.Context(max_w=640, max_h=480, chunk_pairs=1, max_pairs=1)
+    yield c
+    c.close()
+
+
+def same_bits(a, b):
+    a = np.ascontiguousarray(a).view(np.float64); b = np.ascontiguousarray(b).view(np.float64)
+    return (a.view(np.uint64) == b.view(np.uint64)) | (np.isnan(a) & np.isnan(b))
+
+
+def poly_cases():
+    rng = np.random.default_rng(0)
+    polys = [rng.standard_normal(11) for _ in range(300)]
+    polys += [rng.standard_normal(11) * 10.0 ** rng.uniform(-6, 6, 11) for _ in range(300)]       # badly scaled
+    polys += [np.poly(rng.standard_normal(10) * 3)[::-1] for _ in range(100)]                     # ten real roots
+    for mult in (2, 3, 4):                                                                        # repeated roots
+        r = rng.standard_normal(10 - mult + 1) * 2
+        polys.append(np.poly(np.concatenate([r, np.repeat(r[:1], mult - 1)]))[::-1])
+    polys += [np.r_[np.zeros(10), 1.0], np.r_[-1.0, np.zeros(9), 1.0], np.r_[np.zeros(9), 1.0, 1.0]]   # x^10, x^10 - 1, x^10 + x^9
+    for k in (10, 9, 5, 2):                                                                       # leading coefficients 0: lower degree
+        c = rng.standard_normal(11); c[k:] = 0; polys.append(c)
+    c = rng.standard_normal(11); c[10] = 1e-17; polys.append(c)                                   # below DBL_EPSILON: dropped too
+    polys += [rng.standard_normal(11) * 1e300, rng.standard_normal(11) * 1e150,                   # overflow -> inf / NaN
+              rng.standard_normal(11) * 1e-300 + np.eye(11)[10], np.zeros(11)]
+    return np.array(polys)
+
+
+def test_solve_poly10_bit_exact(ctx, oracle):
+    polys = poly_cases()
+    with np.errstate(all="ignore"):
+        ro = np.array([oracle.solve_poly10(c) for c in polys])
+    rg = ctx.debug_solve_poly10(polys)
+    ok = same_bits(ro, rg).reshape(len(polys), -1).all(axis=1)
+    assert ok.all(), np.where(~ok)[0]
+    # sanity of the reference itself: well-separated real roots are found
+    c = np.poly(np.arange(1, 11))[::-1]
+    assert np.allclose(np.sort(ctx.debug_solve_poly10(c)[0].real), np.arange(1, 11), atol=1e-6)
+
+
+def test_five_point_bit_exact(ctx, oracle, K02):
+    rng = np.random.default_rng(1)
+    X1, X2 = [], []
+    for seed in range(40):
+        x1, x2, *_ = two_view(seed, 60, K02, noise=0.3, outliers=10)
+        n1 = (x1 - K02[:2, 2]) / K02[0, 0]; n2 = (x2 - K02[:2, 2]) / K02[0, 0]
+        for _ in range(25):
+            idx = rng.choice(60, 5, replace=False)
+            X1.append(n1[idx]); X2.append(n2[idx])
+    # degenerate samples: a repeated correspondence, all five the same, collinear points, no motion, zeros
+    X1.append(np.r_[X1[0][:4], X1[0][:1]]); X2.append(np.r_[X2[0][:4], X2[0][:1]])
+    X1.append(np.repeat(X1[1][:1], 5, 0)); X2.append(np.repeat(X2[1][:1], 5, 0))
+    t = np.linspace(-0.4, 0.4, 5)[:, None]
+    X1.append(np.hstack([t, 0.5 * t + 0.1])); X2.append(np.hstack([t + 0.02, 0.5 * t + 0.1]))
+    X1.append(X1[2].copy()); X2.append(X1[2].copy())
+    X1.append(np.zeros((5, 2))); X2.append(np.zeros((5, 2)))
+    X1 = np.array(X1, np.float64); X2 = np.array(X2, np.float64)
+    cnt, E = ctx.debug_five_point(X1, X2)
+    assert cnt[:1000].mean() > 2          # the solver does find models on ordinary samples
+    for i in range(len(X1)):
+        with np.errstate(all="ignore"):
+            Eo = oracle.five_point(X1[i], X2[i])
+        assert len(Eo) == cnt[i], i
+        assert same_bits(Eo, E[i, :cnt[i]]).all(), i
+        assert not E[i, cnt[i]:].any()
+
+
+def test_minimal_solver_arguments(ctx):
+    from visual_slam_amd._lib import VoError
+    assert ctx.debug_solve_poly10(np.zeros((0, 11))).shape == (0, 10)
+    with pytest.raises(VoError):
+        ctx._check(ctx.lib.vo_debug_minimal_solver(ctx.h, 2, None, 1, None))

@@ -11,7 +11,7 @@ def child(so):
     if so != "-":
         _lib.SO_PATH = os.path.abspath(so)
     lib = _lib.load()
-    n = 32
+    n = int(os.environ.get("EXP_N", "32"))
     if os.environ.get("EXP_KITTI"):      # the bundled KITTI frames instead of the synthetic generator
         from visual_slam_amd import loader
         fr = [loader.decode_gray(p) for p in loader.load_image_paths(os.path.join(ROOT, "tests", "golden", "kitti02"))]

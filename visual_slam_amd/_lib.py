@@ -36,7 +36,7 @@ PAIR_DTYPE = np.dtype([("T", "<f8", (4, 4)), ("n_kp1", "<i4"), ("n_kp2", "<i4"),
 EXPORTS = [
     "vo_default_orb_params", "vo_ctx_create", "vo_ctx_destroy", "vo_last_error", "vo_orb_detect_compute", "vo_match_knn2_ratio",
     "vo_match_knn2", "vo_find_essential_ransac", "vo_recover_pose", "vo_triangulate", "vo_pairs_run_device", "vo_pairs_run", "vo_sequence_run_device", "vo_sequence_run", "vo_ba_plan_create", "vo_ba_plan_destroy", "vo_ba_pass_device", "vo_ba_pass",
-    "vo_match_knn2_ratio_noalloc", "vo_get_matches", "vo_pairs_triangulate", "vo_pairs_submit_device", "vo_sequence_submit_device", "vo_pairs_wait", "vo_debug_read", "vo_set_debug_stop", "vo_set_kernel_timing", "vo_get_kernel_timing",
+    "vo_match_knn2_ratio_noalloc", "vo_get_matches", "vo_pairs_triangulate", "vo_pairs_submit_device", "vo_sequence_submit_device", "vo_pairs_wait", "vo_debug_read", "vo_debug_minimal_solver", "vo_set_debug_stop", "vo_set_kernel_timing", "vo_get_kernel_timing",
 ]
 
 _lib = None
@@ -87,6 +87,7 @@ def load():
     lib.vo_ba_pass.argtypes = [vp] * 12
     lib.vo_debug_read.argtypes = [vp, i, i, i, vp, C.c_long]
     lib.vo_debug_read.restype = C.c_long
+    lib.vo_debug_minimal_solver.argtypes = [vp, i, vp, i, vp]
     lib.vo_set_debug_stop.argtypes = [vp, i]
     lib.vo_set_kernel_timing.argtypes = [vp, i]
     lib.vo_get_kernel_timing.argtypes = [vp, vp, vp]
@@ -286,6 +287,21 @@ class Context:
         return out
 
     # ---- diagnostics
+    def debug_solve_poly10(self, coeffs):
+        """the solver's cv::solvePoly on [n, 11] coefficient vectors (ascending powers) -> complex128 [n, 10]"""
+        c = np.ascontiguousarray(coeffs, np.float64).reshape(-1, 11)
+        out = np.zeros((len(c), 20))
+        self._check(self.lib.vo_debug_minimal_solver(self.h, 0, _ptr(c), len(c), _ptr(out)))
+        return out.view(np.complex128)
+
+    def debug_five_point(self, x1, x2):
+        """the five-point minimal solver on [n, 5, 2] normalised correspondences -> (counts int [n], E float64 [n, 10, 3, 3])"""
+        x1 = np.ascontiguousarray(x1, np.float64).reshape(-1, 10); x2 = np.ascontiguousarray(x2, np.float64).reshape(-1, 10)
+        inp = np.ascontiguousarray(np.concatenate([x1, x2], axis=1))
+        out = np.zeros((len(inp), 91))
+        self._check(self.lib.vo_debug_minimal_solver(self.h, 1, _ptr(inp), len(inp), _ptr(out)))
+        return out[:, 0].astype(np.int64), out[:, 1:].reshape(-1, 10, 3, 3).copy()
+
     def set_debug_stop(self, stage):
         self._check(self.lib.vo_set_debug_stop(self.h, stage))
 

@@ -923,6 +923,25 @@ int vo_pairs_run(vo_ctx* c, const uint8_t* imgsA, const uint8_t* imgsB, int B, i
 }
 
 // -------------------------------------------------------------------- stage read-back
+int vo_debug_minimal_solver(vo_ctx* c, int mode, const double* in, int n, double* out) {
+    if (!c) return VO_ERR_INVALID;
+    REFUSE_IN_FLIGHT(c, "vo_debug_minimal_solver");
+    if ((mode != 0 && mode != 1) || !in || !out || n < 0) return vo_fail(c, VO_ERR_INVALID, "vo_debug_minimal_solver: bad arguments");
+    if (n == 0) return VO_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t in_b = (size_t)n * (mode == 0 ? 11 : 20) * 8, out_b = (size_t)n * (mode == 0 ? 20 : 91) * 8;
+    DevBuf d_in, d_out;   // a test hook: its buffers live for the call only
+    ALLOC(c, d_in, in_b);
+    int rc = dev_alloc(c, d_out, out_b);
+    if (rc != VO_OK) { dev_free(d_in); return rc; }
+    if (hipMemcpyAsync(d_in.p, in, in_b, hipMemcpyHostToDevice, c->stream) != hipSuccess) rc = vo_fail(c, VO_ERR_HIP, "vo_debug_minimal_solver: copy in");
+    if (rc == VO_OK) rc = vo_launch_debug_minimal(c, mode, (const double*)d_in.p, n, (double*)d_out.p, c->stream);
+    if (rc == VO_OK && hipMemcpyAsync(out, d_out.p, out_b, hipMemcpyDeviceToHost, c->stream) != hipSuccess) rc = vo_fail(c, VO_ERR_HIP, "vo_debug_minimal_solver: copy out");
+    if (hipStreamSynchronize(c->stream) != hipSuccess && rc == VO_OK) rc = vo_fail(c, VO_ERR_HIP, "vo_debug_minimal_solver: kernel failed");
+    dev_free(d_in); dev_free(d_out);
+    return rc;
+}
+
 long vo_debug_read(vo_ctx* c, int what, int index, int level, void* out, long bytes) {
     if (!c || (!c->geom_valid && what <= VO_DBG_DESCRIPTORS)) return VO_ERR_INVALID;
     if (hipSetDevice(c->device) != hipSuccess) return VO_ERR_HIP;

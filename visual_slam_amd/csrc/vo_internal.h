@@ -198,6 +198,7 @@ int vo_launch_ransac(vo_ctx* c, int P, const double K[9], double prob, double th
 int vo_launch_recover(vo_ctx* c, int P, const double K[9], double dist_thresh, hipStream_t st);
 int vo_launch_triangulate_pairs(vo_ctx* c, int P, const double* dPm, const long* doffsets, float* dX3, float2* dq1, float2* dq2, hipStream_t st);
 int vo_launch_triangulate(vo_ctx* c, const double* dP, const float* dx1, const float* dx2, int n, float* dX4, hipStream_t st);
+int vo_launch_debug_minimal(vo_ctx* c, int mode, const double* d_in, int n, double* d_out, hipStream_t st);
 
 #define VO_HYP_ROUND 64   // RANSAC hypotheses solved per round
 struct PoseWork {

@@ -175,6 +175,12 @@ __device__ __forceinline__ Cx cdiv(Cx a, Cx b) {
 }
 
 #define DK_T 64  // threads per solver workgroup
+#ifndef DK_SWEEPS
+#define DK_SWEEPS 300  // cv::solvePoly's maxIters at the reference's call (timing experiments lower it)
+#endif
+#ifndef DK_SWEEP_MODE
+#define DK_SWEEP_MODE 1   // 0: round 1's branchy root updates (A/B runs); 1: straight-line updates with a rare redo
+#endif
 
 // cv::solvePoly(coeffs, roots, 300): Durand-Kerner, in-place (Gauss-Seidel) updates, start
 // (1+i)^k.  Degree-10 fast path: roots and coefficients live in registers (every index is a
@@ -213,6 +219,70 @@ __device__ __forceinline__ void dk_update_root(const double (&coef)[11], double 
     rre[i] = p.re - num.re;
     rim[i] = p.im - num.im;
     maxDiff = fmax(maxDiff, sqrt(num.re * num.re + num.im * num.im));
+}
+
+// One root's update from arrays in memory, index at run time: the rare path of dk_update_root_fast below.
+__device__ __noinline__ void dk_update_root_mem(const double* coef, double* rre, double* rim, int i, double* maxSq) {
+    const Cx p{rre[i], rim[i]};
+    Cx num{coef[10], 0}, denom{coef[10], 0};
+    int num_same_root = 1;
+    for (int j = 0; j < 10; j++) {
+        num = cadd(cmul(num, p), Cx{coef[9 - j], 0});
+        if (j != i) {
+            const Cx d = csub(p, Cx{rre[j], rim[j]});
+            if (d.re != 0 || d.im != 0) denom = cmul(denom, d);
+            else num_same_root++;
+        }
+    }
+    num = cdiv(num, denom);
+    if (num_same_root > 1 && (num_same_root % 2) == 0) {
+        const double old_re = num.re, old_im = num.im;
+        const int times = num_same_root / 2;
+        for (int j = 0; j < times; j++) {
+            num.re = old_re * old_re + old_im * old_im;
+            num.re = sqrt(num.re);
+            num.re += old_re;
+            num.im = num.re - old_re;
+            num.re /= 2;
+            num.re = sqrt(num.re);
+            num.im /= 2;
+            num.im = sqrt(num.im);
+            if (old_re < 0) num.im = -num.im;
+        }
+    }
+    rre[i] = p.re - num.re;
+    rim[i] = p.im - num.im;
+    *maxSq = fmax(*maxSq, num.re * num.re + num.im * num.im);
+}
+
+// dk_update_root without its 9 "is this factor exactly zero" branches per root (they cost more instructions than the
+// arithmetic they guard and cut the update into ten basic blocks).  A factor (0, 0) leaves the product (+-0, +-0) or NaN
+// whatever follows, so a product that is neither proves that no factor was zero, and then this straight-line code has
+// done exactly what the branchy loop does (num_same_root stays 1).  Otherwise (coincident roots, or a product that
+// underflowed) the update is redone by the generic code above.  maxSq tracks |step|^2, not |step|: the sweep loop only
+// asks whether the largest step is > 0, and sqrt(x) > 0 exactly when x > 0.
+__device__ __forceinline__ void dk_update_root_fast(const double (&coef)[11], double (&rre)[10], double (&rim)[10], const int i, double& maxSq) {
+    const Cx p{rre[i], rim[i]};
+    Cx num{coef[10], 0}, denom{coef[10], 0};
+#pragma unroll
+    for (int j = 0; j < 10; j++) {
+        num = cadd(cmul(num, p), Cx{coef[9 - j], 0});
+        if (j != i) denom = cmul(denom, csub(p, Cx{rre[j], rim[j]}));
+    }
+    if (__builtin_expect((denom.re != 0 || denom.im != 0) && denom.re == denom.re && denom.im == denom.im, 1)) {
+        num = cdiv(num, denom);
+        rre[i] = p.re - num.re;
+        rim[i] = p.im - num.im;
+        maxSq = fmax(maxSq, num.re * num.re + num.im * num.im);
+    } else {
+        double t[31];
+        for (int k = 0; k < 10; k++) { t[k] = rre[k]; t[10 + k] = rim[k]; }
+        for (int k = 0; k <= 10; k++) t[20 + k] = coef[k];
+        double m = maxSq;
+        dk_update_root_mem(t + 20, t, t + 10, i, &m);
+        rre[i] = t[i]; rim[i] = t[10 + i];
+        maxSq = m;
+    }
 }
 
 // generic degree (leading coefficients ~ 0): same algorithm on local arrays
@@ -279,7 +349,8 @@ __device__ void solve_poly10(const double* coeffs_in, double* out_re, double* ou
                 p = cmul(p, r);
             }
         }
-        for (int iter = 0; iter < 300; iter++) {
+#if DK_SWEEP_MODE == 0
+        for (int iter = 0; iter < DK_SWEEPS; iter++) {
             double maxDiff = 0;
             dk_update_root(coef, rre, rim, 0, maxDiff);
             dk_update_root(coef, rre, rim, 1, maxDiff);
@@ -293,6 +364,22 @@ __device__ void solve_poly10(const double* coeffs_in, double* out_re, double* ou
             dk_update_root(coef, rre, rim, 9, maxDiff);
             if (maxDiff <= 0) break;
         }
+#else
+        for (int iter = 0; iter < DK_SWEEPS; iter++) {
+            double maxSq = 0;
+            dk_update_root_fast(coef, rre, rim, 0, maxSq);
+            dk_update_root_fast(coef, rre, rim, 1, maxSq);
+            dk_update_root_fast(coef, rre, rim, 2, maxSq);
+            dk_update_root_fast(coef, rre, rim, 3, maxSq);
+            dk_update_root_fast(coef, rre, rim, 4, maxSq);
+            dk_update_root_fast(coef, rre, rim, 5, maxSq);
+            dk_update_root_fast(coef, rre, rim, 6, maxSq);
+            dk_update_root_fast(coef, rre, rim, 7, maxSq);
+            dk_update_root_fast(coef, rre, rim, 8, maxSq);
+            dk_update_root_fast(coef, rre, rim, 9, maxSq);
+            if (maxSq <= 0) break;
+        }
+#endif
 #pragma unroll
         for (int i = 0; i < 10; i++) { out_re[i] = rre[i]; out_im[i] = rim[i]; }
     } else {
@@ -845,6 +932,32 @@ int vo_launch_recover(vo_ctx* c, int P, const double K[9], double dist_thresh, h
     hipLaunchKernelGGL(k_cheirality, dim3((kp_cap + 63) / 64, P, 4), dim3(64), 0, st, pw, (const int*)c->nmatch(), kp_cap,
                        (const float2*)c->q1(), (const float2*)c->q2(), nk, dist_thresh, vote);
     hipLaunchKernelGGL(k_pose_pick, dim3(pb), dim3(64), 0, st, pw, P, vote);
+    HIP_TRY(c, hipGetLastError());
+    return VO_OK;
+}
+
+// Parity hook for the minimal solver (vo_debug_minimal_solver): one lane per case.
+// mode 0: in = 11 coefficients (ascending powers), out = 10 roots as (re, im) pairs
+// mode 1: in = x1[5][2], x2[5][2] (normalised points), out = model count followed by 10 row-major E
+__global__ __launch_bounds__(DK_T) void k_debug_minimal(int mode, const double* __restrict__ in, int n, double* __restrict__ out) {
+    const int t = blockIdx.x * DK_T + threadIdx.x;
+    if (t >= n) return;
+    if (mode == 0) {
+        double c[11], re[10], im[10];
+        for (int i = 0; i < 11; i++) c[i] = in[(size_t)t * 11 + i];
+        solve_poly10(c, re, im);
+        for (int i = 0; i < 10; i++) { out[(size_t)t * 20 + 2 * i] = re[i]; out[(size_t)t * 20 + 2 * i + 1] = im[i]; }
+    } else {
+        double x1[10], x2[10], Eb[90];
+        for (int i = 0; i < 10; i++) { x1[i] = in[(size_t)t * 20 + i]; x2[i] = in[(size_t)t * 20 + 10 + i]; }
+        for (int i = 0; i < 90; i++) Eb[i] = 0;
+        const int nm = five_point(x1, x2, Eb);
+        out[(size_t)t * 91] = nm;
+        for (int i = 0; i < 90; i++) out[(size_t)t * 91 + 1 + i] = i < 9 * nm ? Eb[i] : 0.0;
+    }
+}
+int vo_launch_debug_minimal(vo_ctx* c, int mode, const double* d_in, int n, double* d_out, hipStream_t st) {
+    hipLaunchKernelGGL(k_debug_minimal, dim3((n + DK_T - 1) / DK_T), dim3(DK_T), 0, st, mode, d_in, n, d_out);
     HIP_TRY(c, hipGetLastError());
     return VO_OK;
 }
