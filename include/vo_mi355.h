@@ -155,7 +155,9 @@ int vo_pairs_wait(vo_ctx* ctx);
 int vo_sequence_submit_device(vo_ctx* ctx, const uint8_t* imgs_dev, int F, int w, int h, int stride,
                               const double K[9], double ratio, vo_pair_result* out_host, void* stream);
 
-/* Same with host images (adds the H2D copy). */
+/* Same with host images: each chunk's H2D copy is enqueued on the stream that runs the chunk, so copies overlap the other
+ * chunks' kernels.  Page-locked arrays (hipHostMalloc / hipHostRegister / torch pin_memory) copy asynchronously at PCIe
+ * rate; pageable ones are staged by the calling thread. */
 int vo_pairs_run(vo_ctx* ctx, const uint8_t* imgsA, const uint8_t* imgsB, int B,
                  int w, int h, int stride, const double K[9], double ratio, vo_pair_result* out);
 

@@ -328,6 +328,21 @@ static hipError_t copy_frames_h2d(void* dst, const uint8_t* src, int w, int stri
     return hipMemcpy2D(dst, w, src, stride, w, rows, hipMemcpyHostToDevice);
 }
 
+// The same copy enqueued on a lane's stream: it is ordered after the lane's previous chunk (whose kernels read the staging
+// area it overwrites) and runs beside the other lanes' kernels.  From pinned host memory the call returns at once; from
+// pageable memory it returns when the runtime has taken the source, and the host thread is then what bounds the rate.
+static hipError_t copy_frames_h2d_async(void* dst, const uint8_t* src, int w, int stride, size_t rows, hipStream_t st) {
+    if (stride == w) return hipMemcpyAsync(dst, src, (size_t)w * rows, hipMemcpyHostToDevice, st);
+    return hipMemcpy2DAsync(dst, w, src, stride, w, rows, hipMemcpyHostToDevice, st);
+}
+// a lane's part of the staging buffer (max_frames frames of max_w x max_h each)
+static uint8_t* lane_stage(vo_ctx* c, const vo_ctx* L) {
+    size_t li = 0;
+    for (size_t i = 0; i < c->lanes.size(); i++)
+        if (c->lanes[i] == L) li = i + 1;
+    return (uint8_t*)c->d_img.p + li * (size_t)c->max_frames * c->max_w * c->max_h;
+}
+
 int vo_orb_detect_compute(vo_ctx* c, const uint8_t* img, int w, int h, int stride, vo_keypoint* kps, uint8_t* desc, int cap, int* n) {
     if (!c) return VO_ERR_INVALID;
     if (!img || !n || w <= 0 || h <= 0 || stride < w) return vo_fail(c, VO_ERR_INVALID, "vo_orb_detect_compute: bad arguments");
@@ -546,15 +561,9 @@ static int propagate_geometry(vo_ctx* c) {
 // RANSAC rounds are issued only after detect + match of batch b+1 have been enqueued, so they overlap them; the pair
 // arrays the two stages share exist twice (vo_ctx::slot).  In the timing mode everything runs on ONE stream, one
 // kernel at a time (HIP events bracket every launch).
-// Host-image entry points pass a Stager: before the chunks of pairs [p0, p0 + pairs) of a batch are enqueued, the lanes
-// are drained (they may still read the staging buffer) and prepare(first_pair, n) copies the next n pairs' frames up.
-struct Stager {
-    std::function<int(int, int)> prepare;
-    int pairs = 0;
-};
-
+// The host-image entry points put a chunk's host-to-device copy at the head of its chunk() on the same lane stream.
 static int run_batches(vo_ctx* c, int B, int cp, const double K[9], vo_pair_result* out, hipStream_t user,
-                       const std::function<int(vo_ctx*, hipStream_t, int, int, int)>& chunk, const Stager* stg = nullptr) {
+                       const std::function<int(vo_ctx*, hipStream_t, int, int, int)>& chunk) {
     if (c->n_submitted != c->n_waited) return vo_fail(c, VO_ERR_INVALID, "a submission is in flight on this context: call vo_pairs_wait first");
     const bool serial = c->timing;
     const int nl = serial ? 1 : 1 + (int)c->lanes.size();
@@ -580,12 +589,6 @@ static int run_batches(vo_ctx* c, int B, int cp, const double K[9], vo_pair_resu
         c->slot = slot;
         unsigned used = 0;
         for (int p0 = 0; p0 < Pb; p0 += cp, nchunk++) {
-            if (stg && p0 % stg->pairs == 0) {
-                for (hipStream_t q : lst)
-                    if (hipStreamSynchronize(q) != hipSuccess) return drain(vo_fail(c, VO_ERR_HIP, "hipStreamSynchronize failed"));
-                rc = stg->prepare(b0 + p0, std::min(stg->pairs, Pb - p0));
-                if (rc != VO_OK) return drain(rc);
-            }
             const int li = nchunk % nl;
             vo_ctx* L = lane(li);
             L->slot = slot;
@@ -869,25 +872,20 @@ int vo_sequence_run(vo_ctx* c, const uint8_t* imgs, int F, int w, int h, int str
     int rc = vo_build_geometry(c, w, h);
     if (rc != VO_OK) return rc;
     propagate_geometry(c);
-    // frames are staged through device memory one chunk per lane at a time (n pairs = n + 1 frames; pieces share one frame)
+    // frames are staged through device memory chunk by chunk, each copy on its lane's stream (n pairs = n + 1 frames: the
+    // frame two chunks share is copied twice)
     const long fs = (long)w * h;
-    const int cp = std::min(c->chunk_pairs, 2 * c->chunk_pairs - 1);
-    Stager stg;
-    stg.pairs = (int)std::min<long>((long)cp * (1 + (long)c->lanes.size()), (long)(c->d_img.bytes / fs) - 1);
-    if (stg.pairs < cp) return vo_fail(c, VO_ERR_CAPACITY, "vo_sequence_run: staging buffer too small");
-    stg.pairs -= stg.pairs % cp;
-    stg.prepare = [&](int first, int n) {
-        HIP_TRY(c, copy_frames_h2d(c->d_img.p, imgs + (long)first * stride * h, w, stride, (size_t)h * (n + 1)));
-        return (int)VO_OK;
-    };
+    const int cp = std::min(c->chunk_pairs, c->max_frames - 1);
     return run_batches(c, F - 1, cp, K, out, nullptr, [&](vo_ctx* L, hipStream_t st, int b0, int p0, int Pc) {
-        const uint8_t* first = (const uint8_t*)c->d_img.p + (long)(p0 % stg.pairs) * fs;
+        uint8_t* first = lane_stage(c, L);
+        if (copy_frames_h2d_async(first, imgs + (long)(b0 + p0) * stride * h, w, stride, (size_t)h * (Pc + 1), st) != hipSuccess)
+            return vo_fail(L, VO_ERR_HIP, "vo_sequence_run: host-to-device copy failed");
         FrameSrc src{first, first, Pc + 1, w, fs};
         L->last_src = src; L->last_frames = Pc + 1;
         int r = vo_launch_detect(L, src, Pc + 1, st);
         if (r != VO_OK) return r;
         return vo_launch_match_impl(L, Pc, 1, ratio, p0, nullptr, st);
-    }, &stg);
+    });
 }
 
 int vo_pairs_run(vo_ctx* c, const uint8_t* imgsA, const uint8_t* imgsB, int B, int w, int h, int stride, const double K[9], double ratio,
@@ -899,27 +897,20 @@ int vo_pairs_run(vo_ctx* c, const uint8_t* imgsA, const uint8_t* imgsB, int B, i
     int rc = vo_build_geometry(c, w, h);
     if (rc != VO_OK) return rc;
     propagate_geometry(c);
-    // frames are staged through device memory one chunk per lane at a time: A frames in the first half of d_img, B in the second
+    // frames are staged through device memory chunk by chunk, each copy on its lane's stream: A frames, then B frames
     const long fs = (long)w * h;
-    Stager stg;
-    stg.pairs = (int)std::min<long>((long)c->chunk_pairs * (1 + (long)c->lanes.size()), (long)(c->d_img.bytes / fs) / 2);
-    if (stg.pairs < c->chunk_pairs) return vo_fail(c, VO_ERR_CAPACITY, "vo_pairs_run: staging buffer too small");
-    stg.pairs -= stg.pairs % c->chunk_pairs;
-    uint8_t* dA = (uint8_t*)c->d_img.p;
-    uint8_t* dB = dA + (long)stg.pairs * fs;
-    stg.prepare = [&](int first, int n) {
-        HIP_TRY(c, copy_frames_h2d(dA, imgsA + (long)first * stride * h, w, stride, (size_t)h * n));
-        HIP_TRY(c, copy_frames_h2d(dB, imgsB + (long)first * stride * h, w, stride, (size_t)h * n));
-        return (int)VO_OK;
-    };
     return run_batches(c, B, c->chunk_pairs, K, out, nullptr, [&](vo_ctx* L, hipStream_t st, int b0, int p0, int Pc) {
-        const long q = p0 % stg.pairs;
-        FrameSrc src{dA + q * fs, dB + q * fs, Pc, w, fs};
+        uint8_t* dA = lane_stage(c, L);
+        uint8_t* dB = dA + (long)Pc * fs;
+        if (copy_frames_h2d_async(dA, imgsA + (long)(b0 + p0) * stride * h, w, stride, (size_t)h * Pc, st) != hipSuccess ||
+            copy_frames_h2d_async(dB, imgsB + (long)(b0 + p0) * stride * h, w, stride, (size_t)h * Pc, st) != hipSuccess)
+            return vo_fail(L, VO_ERR_HIP, "vo_pairs_run: host-to-device copy failed");
+        FrameSrc src{dA, dB, Pc, w, fs};
         L->last_src = src; L->last_frames = 2 * Pc;
         int r = vo_launch_detect(L, src, 2 * Pc, st);
         if (r != VO_OK) return r;
         return vo_launch_match_impl(L, Pc, Pc, ratio, p0, nullptr, st);
-    }, &stg);
+    });
 }
 
 // -------------------------------------------------------------------- stage read-back
