@@ -6,8 +6,8 @@
 //   k_pyramid (x7)  cascaded INTER_LINEAR_EXACT resize, 8.8 fixed point (4 px x 4 rows per lane)
 //   k_fast_tiles    FAST-9/16 + cornerScore + 3x3 NMS on 60x30 LDS tiles: pretest -> polarity
 //                   queues -> arc scoring -> queue-driven NMS -> bitmap-rank compaction   [VALU bound]
-//   k_fast_scan     raster-order offsets of every (row, tile column) segment
-//   k_fast_emit     candidates to per-level lists in raster order
+//   k_fast_emit     candidates to per-level lists in raster order (one workgroup per row of tiles prefixes the per-tile
+//                   and per-(row, tile) counts of k_fast_tiles along both axes in LDS)
 //   k_select        KeyPointsFilter::retainBest: data-parallel replay of libstdc++
 //                   nth_element + partition (tests/introselect_model.py), lists in LDS
 //   k_harris        7x7 Harris response at the kept candidates
@@ -314,7 +314,7 @@ __device__ __forceinline__ int lanes_below(unsigned long long m) {
 #endif
 __global__ __launch_bounds__(256) void k_fast_tiles(const Geom* __restrict__ g, FrameSrc src, const uint8_t* __restrict__ pyr,
                                                     const TileDesc* __restrict__ tiles, uint32_t* __restrict__ tile_list,
-                                                    uint8_t* __restrict__ seg_cnt, int nframes) {
+                                                    uint8_t* __restrict__ seg_cnt, uint32_t* __restrict__ tile_cnt, int nframes) {
     __shared__ __attribute__((aligned(16))) uint8_t px[PXR * PXP];
     __shared__ __attribute__((aligned(16))) uint8_t sc[32 * SCP + 8];      // scores of the 64 x 32 positions
     __shared__ uint32_t bm[64];          // survivors (NMS + border) of the 60 x 30 outputs, one bit each: row r = dwords 2r, 2r+1
@@ -482,6 +482,7 @@ __global__ __launch_bounds__(256) void k_fast_tiles(const Geom* __restrict__ g, 
         const int v = lane < 2 * VO_TILE_H ? (int)__popc(bm[lane]) : 0;
         const int incl = wave_incl_scan(v);
         bmpre[lane] = incl - v;
+        if (lane == 63) tile_cnt[(long)f * g->ntiles + t] = (uint32_t)incl;   // survivors of the tile: k_fast_emit sums these over the earlier tile rows
         const int nxt = __shfl_down(v, 1);
         const int r = lane >> 1;
         if ((lane & 1) == 0 && r < VO_TILE_H && td.ty * VO_TILE_H + r < L.ih)
@@ -499,88 +500,87 @@ __global__ __launch_bounds__(256) void k_fast_tiles(const Geom* __restrict__ g, 
     }
 }
 
-// exclusive scan over the (row, tile column) segments of one level in raster order
-__global__ __launch_bounds__(256) void k_fast_scan(const Geom* __restrict__ g, const uint8_t* __restrict__ seg_cnt,
-                                                   uint32_t* __restrict__ seg_ofs, int* __restrict__ cnt_fast) {
-    __shared__ int wtot[4];
-    const int l = blockIdx.x, f = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const LevelGeom& L = g->lv[l];
-    const int S = L.ih * L.ntx;
-    const uint8_t* cp = seg_cnt + (long)f * g->nsegs + L.seg_base;
-    uint32_t* op = seg_ofs + (long)f * g->nsegs + L.seg_base;
-    int running = 0;
-    for (int base = 0; base < S; base += 256 * 16) {
-        const int i0 = base + tid * 16;
-        uint8_t v[16];
-        if (i0 + 16 <= S) {
-            uint4 q = *reinterpret_cast<const uint4*>(cp + i0);
-            memcpy(v, &q, 16);
-        } else {
-#pragma unroll
-            for (int j = 0; j < 16; j++) v[j] = (i0 + j < S) ? cp[i0 + j] : 0;
-        }
-        int sum = 0;
-#pragma unroll
-        for (int j = 0; j < 16; j++) sum += v[j];
-        int incl = sum;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            int u = __shfl_up(incl, o);
-            if (lane >= o) incl += u;
-        }
-        if (lane == 63) wtot[wave] = incl;
-        __syncthreads();
-        int wbase = 0, tot = 0;
-        for (int w2 = 0; w2 < 4; w2++) {
-            if (w2 < wave) wbase += wtot[w2];
-            tot += wtot[w2];
-        }
-        int pre = running + wbase + incl - sum;
-#pragma unroll
-        for (int j = 0; j < 16; j++) {
-            if (i0 + j < S) op[i0 + j] = pre;
-            pre += v[j];
-        }
-        running += tot;
-        __syncthreads();
-    }
-    if (tid == 0) cnt_fast[f * VO_MAX_LEVELS + l] = running;
-}
-
-// tile lists -> per-level candidate lists in raster order: key = FAST score, payload = packed x,y,score
-__global__ __launch_bounds__(64) void k_fast_emit(const Geom* __restrict__ g, const TileDesc* __restrict__ tiles,
-                                                  const uint32_t* __restrict__ tile_list, const uint8_t* __restrict__ seg_cnt,
-                                                  const uint32_t* __restrict__ seg_ofs, float* __restrict__ key, uint32_t* __restrict__ payload, int nframes) {
-    __shared__ int rowstart[33];
-    __shared__ uint32_t rowofs[32];
-    const VBlock vb = xcd_block(g->ntiles, 1, nframes);
+// tile lists -> per-level candidate lists in raster order: key = FAST score, payload = packed x,y,score.
+// A candidate's slot is the number of candidates before it in raster order.  One workgroup takes one ROW OF TILES
+// (up to 30 image rows x ntx tile columns): the slot of entry e of tile x in image row r is
+//   (all candidates of the tile rows above: sum of their tiles' totals)
+//   + (rows above r in this tile row, all tile columns) + (row r, tile columns left of x)      -> rowbase[r] + rowl[r][x]
+//   + (e - entries of tile x in the rows above r)                                                -> e - colpre[x][r]
+// all from the tile row's block of per-(row, tile) counts (rows * ntx bytes, contiguous) that k_fast_tiles wrote, prefixed
+// along both axes in LDS.  (Round 1 ran a scan kernel per level between k_fast_tiles and a per-tile emit kernel.)
+// The workgroup of a level's last tile row also writes the level's total.
+#define EM_MAXX 72   // tile columns: (4095 - 62) / 60 rounded up is 68
+__global__ __launch_bounds__(256) void k_fast_emit(const Geom* __restrict__ g, const uint32_t* __restrict__ tile_list,
+                                                   const uint8_t* __restrict__ seg_cnt, const uint32_t* __restrict__ tile_cnt,
+                                                   int* __restrict__ cnt_fast, float* __restrict__ key, uint32_t* __restrict__ payload,
+                                                   int ntrows, int nframes) {
+    __shared__ uint8_t A[VO_TILE_H * EM_MAXX];         // counts [r][x], pitch ntx
+    __shared__ uint16_t rowl[VO_TILE_H * EM_MAXX];     // candidates of row r left of tile x
+    __shared__ uint16_t colpre[EM_MAXX * 32];          // candidates of tile x above row r
+    __shared__ int rowtot[32], rowbase[32], tiletot[EM_MAXX + 1], tilepre[EM_MAXX + 1], wsum[4];
+    const VBlock vb = xcd_block(ntrows, 1, nframes);
     if (!vb.valid) return;
-    const int t = vb.x, f = vb.f, lane = threadIdx.x;
-    const TileDesc td = tiles[t];
-    const LevelGeom& L = g->lv[td.level];
-    const int rows = min(VO_TILE_H, L.ih - td.ty * VO_TILE_H);
-    int c = 0;
-    if (lane < rows) {
-        long s = (long)f * g->nsegs + L.seg_base + (long)(td.ty * VO_TILE_H + lane) * L.ntx + td.tx;
-        c = seg_cnt[s];
-        rowofs[lane] = seg_ofs[s];
+    const int f = vb.f, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int l = 0, ty = vb.x;
+    while (l < g->nlevels - 1 && ty >= g->lv[l].nty) { ty -= g->lv[l].nty; l++; }
+    const LevelGeom& L = g->lv[l];
+    const int ntx = L.ntx;
+    if (vb.x == 0 && tid < g->nlevels && g->lv[tid].ntx * g->lv[tid].nty == 0) cnt_fast[f * VO_MAX_LEVELS + tid] = 0;   // levels without tiles
+    const int rows = min(VO_TILE_H, L.ih - ty * VO_TILE_H);
+    const int nbytes = rows * ntx;
+    const uint8_t* blk = seg_cnt + (long)f * g->nsegs + L.seg_base + (long)ty * VO_TILE_H * ntx;
+    for (int i = tid; i < nbytes; i += 256) A[i] = blk[i];
+    int above = 0;
+    {
+        const uint32_t* tc = tile_cnt + (long)f * g->ntiles + L.tile_base;
+        for (int i = tid; i < ty * ntx; i += 256) above += (int)tc[i];
     }
-    int incl = c;
-#pragma unroll
-    for (int o = 1; o < 32; o <<= 1) {
-        int u = __shfl_up(incl, o);
-        if (lane >= o) incl += u;
-    }
-    if (lane < 32) rowstart[lane + 1] = incl;
-    if (lane == 0) rowstart[0] = 0;
+    above = wave_incl_scan(above);
+    if (lane == 63) wsum[wave] = above;
     __syncthreads();
-    const int total = rowstart[32];
-    const uint32_t* tl = tile_list + ((long)f * g->ntiles + t) * VO_TILE_CAP;
+    above = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    // prefixes along the two axes: lanes 0..rows-1 of wavefront 0 walk their row, lanes of wavefronts 1.. walk a tile column
+    if (tid < rows) {
+        int acc = 0;
+        for (int x = 0; x < ntx; x++) { rowl[tid * ntx + x] = (uint16_t)acc; acc += A[tid * ntx + x]; }
+        rowtot[tid] = acc;
+    } else if (tid >= 64 && tid - 64 < ntx) {
+        const int x = tid - 64;
+        int acc = 0;
+        for (int r = 0; r < rows; r++) { colpre[x * 32 + r] = (uint16_t)acc; acc += A[r * ntx + x]; }
+        tiletot[x] = acc;
+    }
+    __syncthreads();
+    if (wave == 0) {
+        const int v = lane < rows ? rowtot[lane] : 0;
+        const int incl = wave_incl_scan(v);
+        if (lane < rows) rowbase[lane] = above + incl - v;
+        if (lane == 63 && ty == L.nty - 1) cnt_fast[f * VO_MAX_LEVELS + l] = above + incl;
+    } else if (wave == 1) {
+        int carry = 0;
+        for (int x0 = 0; x0 < ntx; x0 += 64) {
+            const int x = x0 + lane;
+            const int v = x < ntx ? tiletot[x] : 0;
+            const int incl = wave_incl_scan(v);
+            if (x < ntx) tilepre[x] = carry + incl - v;
+            carry += __builtin_amdgcn_readlane(incl, 63);
+        }
+        if (lane == 0) tilepre[ntx] = carry;
+    }
+    __syncthreads();
+    const int total = tilepre[ntx];
+    const uint32_t* tl0 = tile_list + ((long)f * g->ntiles + L.tile_base + (long)ty * ntx) * VO_TILE_CAP;
     const long cb = (long)f * g->cand_frame + L.cand_ofs;
-    for (int e = lane; e < total; e += 64) {
-        const uint32_t p = tl[e];
-        const int r = UNPACK_Y(p) - (VO_EDGE + td.ty * VO_TILE_H);   // the tile list is in raster order: the row is in the record
-        long o = cb + rowofs[r] + (e - rowstart[r]);
+    for (int i = tid; i < total; i += 256) {
+        int lo = 0, hi = ntx - 1;                              // the tile whose run of entries holds i
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (tilepre[mid] <= i) lo = mid; else hi = mid - 1;
+        }
+        const int x = lo, e = i - tilepre[x];
+        const uint32_t p = tl0[(long)x * VO_TILE_CAP + e];
+        const int r = UNPACK_Y(p) - (VO_EDGE + ty * VO_TILE_H);   // a tile's list is in raster order: the row is in the record
+        const long o = cb + rowbase[r] + rowl[r * ntx + x] + (e - colpre[x * 32 + r]);
         key[o] = (float)UNPACK_S(p);
         payload[o] = p;
     }
@@ -1418,12 +1418,12 @@ int vo_launch_detect(vo_ctx* c, const FrameSrc& src, int F, hipStream_t st) {
         HIP_TRY(c, hipEventRecord(c->ev_join, c->aux_stream));
     }
     if (g.ntiles > 0) {
-        KT(c, st, VO_K_FAST_TILES, hipLaunchKernelGGL(k_fast_tiles, dim3(pad8(g.ntiles * F)), dim3(256), 0, st, dg, src, pyr, tiles, (uint32_t*)c->d_tile_list.p, (uint8_t*)c->d_seg_cnt.p, F));
-    }
-    KT(c, st, VO_K_FAST_SCAN, hipLaunchKernelGGL(k_fast_scan, dim3(g.nlevels, F), dim3(256), 0, st, dg, (const uint8_t*)c->d_seg_cnt.p, (uint32_t*)c->d_seg_ofs.p, cnt_fast));
-    if (g.ntiles > 0) {
-        KT(c, st, VO_K_FAST_EMIT, hipLaunchKernelGGL(k_fast_emit, dim3(pad8(g.ntiles * F)), dim3(64), 0, st, dg, tiles, (const uint32_t*)c->d_tile_list.p, (const uint8_t*)c->d_seg_cnt.p,
-                           (const uint32_t*)c->d_seg_ofs.p, key, payload, F));
+        KT(c, st, VO_K_FAST_TILES, hipLaunchKernelGGL(k_fast_tiles, dim3(pad8(g.ntiles * F)), dim3(256), 0, st, dg, src, pyr, tiles, (uint32_t*)c->d_tile_list.p, (uint8_t*)c->d_seg_cnt.p, (uint32_t*)c->d_seg_ofs.p, F));
+        // d_seg_ofs holds the per-tile totals (ntiles <= nsegs per frame)
+        int ntrows = 0;
+        for (int l = 0; l < g.nlevels; l++) ntrows += g.lv[l].nty;
+        KT(c, st, VO_K_FAST_EMIT, hipLaunchKernelGGL(k_fast_emit, dim3(pad8(ntrows * F)), dim3(256), 0, st, dg, (const uint32_t*)c->d_tile_list.p, (const uint8_t*)c->d_seg_cnt.p,
+                           (const uint32_t*)c->d_seg_ofs.p, cnt_fast, key, payload, ntrows, F));
     }
     if (c->debug_stop == 1) { HIP_TRY(c, hipGetLastError()); return VO_OK; }
     // long candidate lists (4K frames: ~10^5 per level) are pass-bound, short ones barrier-bound
