@@ -1105,11 +1105,11 @@ __global__ __launch_bounds__(256) void k_blur(const Geom* __restrict__ g, FrameS
         // interior tile (workgroup-uniform): no reflection, one address and one stride per lane (252 lanes x 14 rows x 5)
         if (tid < 252) {
             const int r0 = tid / 18, k = tid - r0 * 18;
-            const uint8_t* p = img + (long)(y0 - 3 + r0) * pitch + (x0 - 4 + 4 * k);
+            const uint32_t po = (uint32_t)(y0 - 3 + r0) * (uint32_t)pitch + (uint32_t)(x0 - 4 + 4 * k);
             uint32_t* q = reinterpret_cast<uint32_t*>(&sp[r0 * BL_SP + 4 * k]);
             uint32_t v[BL_ROWS / 14];
 #pragma unroll
-            for (int j = 0; j < BL_ROWS / 14; j++) __builtin_memcpy(&v[j], p + 14L * j * pitch, 4);
+            for (int j = 0; j < BL_ROWS / 14; j++) __builtin_memcpy(&v[j], img + (po + 14u * (uint32_t)j * (uint32_t)pitch), 4);
 #pragma unroll
             for (int j = 0; j < BL_ROWS / 14; j++) q[14 * j * BL_SP / 4] = v[j];
         }
@@ -1120,19 +1120,19 @@ __global__ __launch_bounds__(256) void k_blur(const Geom* __restrict__ g, FrameS
         const int r0 = tid / 18, k = tid - r0 * 18;
         const int x = x0 - 4 + 4 * k;
         const bool whole = x >= 0 && x + 3 < L.w;
-        int xb[4];
-#pragma unroll
-        for (int j = 0; j < 4; j++) xb[j] = reflect101c(x + j, L.w);
 #pragma unroll
         for (int j = 0; j < BL_ROWS / 14; j++) {
             const int r = r0 + 14 * j;
             if (r < nrows) {
-                const uint8_t* rp = img + (long)reflect101c(y0 - 3 + r, L.h) * pitch;
+                // 32-bit offsets from the level's (uniform) base
+                const uint32_t ro = (uint32_t)reflect101c(y0 - 3 + r, L.h) * (uint32_t)pitch;
                 uint32_t v;
                 if (whole) {
-                    __builtin_memcpy(&v, rp + x, 4);
+                    __builtin_memcpy(&v, img + (ro + (uint32_t)x), 4);
                 } else {
-                    v = (uint32_t)rp[xb[0]] | ((uint32_t)rp[xb[1]] << 8) | ((uint32_t)rp[xb[2]] << 16) | ((uint32_t)rp[xb[3]] << 24);
+                    v = 0;
+#pragma unroll
+                    for (int b = 0; b < 4; b++) v |= (uint32_t)img[ro + (uint32_t)reflect101c(x + b, L.w)] << (8 * b);
                 }
                 *reinterpret_cast<uint32_t*>(&sp[r * BL_SP + 4 * k]) = v;
             }
@@ -1149,8 +1149,7 @@ __global__ __launch_bounds__(256) void k_blur(const Geom* __restrict__ g, FrameS
         asm volatile("" : "+v"(kw[i]));
     }
     int* rowi = reinterpret_cast<int*>(rowf);
-    for (int i = tid; i < nrows * 16; i += 256) {
-        const int r = i >> 4, c4 = (i & 15) * 4;
+    for (int r = tid >> 4, c4 = (tid & 15) * 4; r < nrows; r += 16) {
         const uint32_t* q = reinterpret_cast<const uint32_t*>(&sp[r * BL_SP + c4]);
         const uint32_t d0 = q[0], d1 = q[1], d2 = q[2];
         // bytes c4+1 .. c4+10 of the window: b[j] = source pixel at output x0+c4+j-3
@@ -1199,10 +1198,11 @@ __global__ __launch_bounds__(256) void k_blur(const Geom* __restrict__ g, FrameS
         if (y0 + r0 >= L.h || x0 + c4 >= L.w) return;
         uint32_t packed[BL_RPL];
         if (mode == 1) {
+            // rows at or beyond nrows were not written by the row pass: they only reach outputs below the level's last row,
+            // which are not stored
             int4 q[BL_RPL + 6];
 #pragma unroll
-            for (int k = 0; k < BL_RPL + 6; k++)
-                if (r0 + k < nrows) q[k] = *reinterpret_cast<const int4*>(&rowi[(r0 + k) * VO_BLUR_TW + c4]);
+            for (int k = 0; k < BL_RPL + 6; k++) q[k] = *reinterpret_cast<const int4*>(&rowi[(r0 + k) * VO_BLUR_TW + c4]);
 #pragma unroll
             for (int o = 0; o < BL_RPL; o++) {
                 packed[o] = 0;
@@ -1219,8 +1219,7 @@ __global__ __launch_bounds__(256) void k_blur(const Geom* __restrict__ g, FrameS
         } else {
             float4 q[BL_RPL + 6];
 #pragma unroll
-            for (int k = 0; k < BL_RPL + 6; k++)
-                if (r0 + k < nrows) q[k] = *reinterpret_cast<const float4*>(&rowf[(r0 + k) * VO_BLUR_TW + c4]);
+            for (int k = 0; k < BL_RPL + 6; k++) q[k] = *reinterpret_cast<const float4*>(&rowf[(r0 + k) * VO_BLUR_TW + c4]);
 #pragma unroll
             for (int o = 0; o < BL_RPL; o++) {
                 packed[o] = 0;
