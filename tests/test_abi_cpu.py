@@ -111,3 +111,27 @@ def test_bench_geometry_matches_the_survey_table():
     assert bench.measured_traffic("k_fast_tiles", 64, 3840, 2160) is None
     t = bench.measured_traffic("k_fast_tiles", 64, 1241, 376)
     assert t is None or 0.5 * 64 * P < t < 2.0 * 64 * P
+
+
+def test_header_is_plain_c_and_matches_the_python_layouts(tmp_path):
+    """include/vo_mi355.h compiles as pedantic C99 (the boundary is a C ABI, not C++), and the struct layouts ctypes / numpy
+    assume in visual_slam_amd/_lib.py are the ones the C compiler produces."""
+    import ctypes as C
+    import subprocess
+    from visual_slam_amd import _lib
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "vo_mi355.h"\n'
+                   'int main(void) { printf("%zu %zu %zu %zu %zu %zu %zu\\n", sizeof(vo_orb_params), sizeof(vo_keypoint), sizeof(vo_pair_result),\n'
+                   '  offsetof(vo_pair_result, n_kp1), offsetof(vo_pair_result, status), offsetof(vo_keypoint, octave), offsetof(vo_orb_params, trig_mode)); return 0; }\n')
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    got = [int(v) for v in subprocess.check_output([str(exe)]).split()]
+    assert got == [C.sizeof(_lib.OrbParams), _lib.KP_DTYPE.itemsize, _lib.PAIR_DTYPE.itemsize, _lib.PAIR_DTYPE.fields["n_kp1"][1],
+                   _lib.PAIR_DTYPE.fields["status"][1], _lib.KP_DTYPE.fields["octave"][1], _lib.OrbParams.trig_mode.offset]
+
+
+def test_c_example_builds_against_the_library():
+    import subprocess
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "examples"), "-s"])
+    out = subprocess.run([os.path.join(ROOT, "examples", "vo_pairs_demo")], capture_output=True, text=True)
+    assert out.returncode == 2 and "usage" in out.stderr        # loads (rpath) and parses arguments; no GPU needed for that

@@ -163,3 +163,34 @@ def test_sequence_reprojection_errors_match_the_dropin():
         ref = vo.calc_reprojection_error(vo.K, vo.D, tj.rodrigues(pose[:3, :3]), pose[:3, 3], out["points"][a:b], out["q2"][a:b])
         assert np.allclose(err[a:b], ref, rtol=1e-9, atol=1e-9)
         assert abs(per_pair[i] - ref.mean()) <= 1e-9 * max(1.0, ref.mean())
+
+
+def test_plain_c_consumer_matches_the_python_binding(kitti02, K02, tmp_path):
+    """examples/vo_pairs_demo.c (gcc, C99, only include/vo_mi355.h) runs the bundled KITTI frames through vo_sequence_run and
+    prints what the ctypes binding returns, number for number."""
+    import subprocess
+    from visual_slam_amd import _lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "examples", "vo_pairs_demo")
+    assert os.path.exists(exe), "examples/vo_pairs_demo is built by __graft_entry__.build() / make -C examples"
+    imgs = np.stack(kitti02)
+    raw = tmp_path / "frames.raw"
+    imgs.tofile(raw)
+    F, h, w = imgs.shape
+    out = subprocess.run([exe, str(raw), str(w), str(h), str(F), repr(float(K02[0, 0])), repr(float(K02[1, 1])), repr(float(K02[0, 2])), repr(float(K02[1, 2])), "2"],
+                         capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    c = _lib.Context(max_w=w, max_h=h, chunk_pairs=2, max_pairs=F - 1)
+    ref = c.sequence_run(imgs, K02)
+    c.close()
+    lines = out.stdout.strip().splitlines()
+    assert len(lines) == F
+    cur = np.eye(4)
+    for i, line in enumerate(lines[:-1]):
+        t = line.split()
+        assert [int(t[3]), int(t[5]), int(t[6]), int(t[8]), int(t[10]), int(t[12])] == \
+            [ref[i]["status"], ref[i]["n_kp1"], ref[i]["n_kp2"], ref[i]["n_match"], ref[i]["n_inlier"], ref[i]["n_good"]]
+        assert np.array_equal(np.array([float(v) for v in t[14:26]]), ref[i]["T"].reshape(-1)[:12])      # %.17g round-trips doubles
+        cur = cur @ np.linalg.inv(ref[i]["T"])
+    pos = np.array([float(v) for v in lines[-1].split()[1:4]])
+    assert np.allclose(pos, cur[:3, 3], atol=1e-12)
