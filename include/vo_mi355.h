@@ -226,7 +226,8 @@ long vo_debug_read(vo_ctx* ctx, int what, int index, int level, void* out, long 
  * and cv::solvePoly in OpenCV 4.x).  Host pointers, n independent cases, one GPU lane each.
  *   mode 0: in = n x 11 polynomial coefficients (ascending powers); out = n x 10 roots as (re, im) pairs
  *   mode 1: in = n x (x1[5][2], x2[5][2]) normalised correspondences; out = n x 91: the model count, then up to ten
- *           row-major 3x3 essential matrices (unused slots 0) */
+ *           row-major 3x3 essential matrices (unused slots 0)
+ *   modes 2, 3: the same two through the 16-lanes-per-case form of the solver that small batches use */
 int vo_debug_minimal_solver(vo_ctx* ctx, int mode, const double* in, int n, double* out);
 /* retainBest permutes its list in place, so the FAST and SEL1 lists only exist if the detect
  * chain is stopped early: 0 = run everything (default), 1 = stop after the FAST lists,

@@ -40,11 +40,12 @@ def poly_cases():
     return np.array(polys)
 
 
-def test_solve_poly10_bit_exact(ctx, oracle):
+@pytest.mark.parametrize("wide", [False, True])     # one lane per polynomial / the 16-lane form small batches use
+def test_solve_poly10_bit_exact(ctx, oracle, wide):
     polys = poly_cases()
     with np.errstate(all="ignore"):
         ro = np.array([oracle.solve_poly10(c) for c in polys])
-    rg = ctx.debug_solve_poly10(polys)
+    rg = ctx.debug_solve_poly10(polys, wide=wide)
     ok = same_bits(ro, rg).reshape(len(polys), -1).all(axis=1)
     assert ok.all(), np.where(~ok)[0]
     # sanity of the reference itself: well-separated real roots are found
@@ -52,7 +53,8 @@ def test_solve_poly10_bit_exact(ctx, oracle):
     assert np.allclose(np.sort(ctx.debug_solve_poly10(c)[0].real), np.arange(1, 11), atol=1e-6)
 
 
-def test_five_point_bit_exact(ctx, oracle, K02):
+@pytest.mark.parametrize("wide", [False, True])
+def test_five_point_bit_exact(ctx, oracle, K02, wide):
     rng = np.random.default_rng(1)
     X1, X2 = [], []
     for seed in range(40):
@@ -69,7 +71,7 @@ def test_five_point_bit_exact(ctx, oracle, K02):
     X1.append(X1[2].copy()); X2.append(X1[2].copy())
     X1.append(np.zeros((5, 2))); X2.append(np.zeros((5, 2)))
     X1 = np.array(X1, np.float64); X2 = np.array(X2, np.float64)
-    cnt, E = ctx.debug_five_point(X1, X2)
+    cnt, E = ctx.debug_five_point(X1, X2, wide=wide)
     assert cnt[:1000].mean() > 2          # the solver does find models on ordinary samples
     for i in range(len(X1)):
         with np.errstate(all="ignore"):
@@ -83,4 +85,4 @@ def test_minimal_solver_arguments(ctx):
     from visual_slam_amd._lib import VoError
     assert ctx.debug_solve_poly10(np.zeros((0, 11))).shape == (0, 10)
     with pytest.raises(VoError):
-        ctx._check(ctx.lib.vo_debug_minimal_solver(ctx.h, 2, None, 1, None))
+        ctx._check(ctx.lib.vo_debug_minimal_solver(ctx.h, 4, None, 1, None))

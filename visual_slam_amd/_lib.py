@@ -287,19 +287,20 @@ class Context:
         return out
 
     # ---- diagnostics
-    def debug_solve_poly10(self, coeffs):
-        """the solver's cv::solvePoly on [n, 11] coefficient vectors (ascending powers) -> complex128 [n, 10]"""
+    def debug_solve_poly10(self, coeffs, wide=False):
+        """the solver's cv::solvePoly on [n, 11] coefficient vectors (ascending powers) -> complex128 [n, 10]; wide: the
+        16-lanes-per-case form that small batches use"""
         c = np.ascontiguousarray(coeffs, np.float64).reshape(-1, 11)
         out = np.zeros((len(c), 20))
-        self._check(self.lib.vo_debug_minimal_solver(self.h, 0, _ptr(c), len(c), _ptr(out)))
+        self._check(self.lib.vo_debug_minimal_solver(self.h, 2 if wide else 0, _ptr(c), len(c), _ptr(out)))
         return out.view(np.complex128)
 
-    def debug_five_point(self, x1, x2):
+    def debug_five_point(self, x1, x2, wide=False):
         """the five-point minimal solver on [n, 5, 2] normalised correspondences -> (counts int [n], E float64 [n, 10, 3, 3])"""
         x1 = np.ascontiguousarray(x1, np.float64).reshape(-1, 10); x2 = np.ascontiguousarray(x2, np.float64).reshape(-1, 10)
         inp = np.ascontiguousarray(np.concatenate([x1, x2], axis=1))
         out = np.zeros((len(inp), 91))
-        self._check(self.lib.vo_debug_minimal_solver(self.h, 1, _ptr(inp), len(inp), _ptr(out)))
+        self._check(self.lib.vo_debug_minimal_solver(self.h, 3 if wide else 1, _ptr(inp), len(inp), _ptr(out)))
         return out[:, 0].astype(np.int64), out[:, 1:].reshape(-1, 10, 3, 3).copy()
 
     def set_debug_stop(self, stage):

@@ -917,10 +917,10 @@ int vo_pairs_run(vo_ctx* c, const uint8_t* imgsA, const uint8_t* imgsB, int B, i
 int vo_debug_minimal_solver(vo_ctx* c, int mode, const double* in, int n, double* out) {
     if (!c) return VO_ERR_INVALID;
     REFUSE_IN_FLIGHT(c, "vo_debug_minimal_solver");
-    if ((mode != 0 && mode != 1) || !in || !out || n < 0) return vo_fail(c, VO_ERR_INVALID, "vo_debug_minimal_solver: bad arguments");
+    if (mode < 0 || mode > 3 || !in || !out || n < 0) return vo_fail(c, VO_ERR_INVALID, "vo_debug_minimal_solver: bad arguments");
     if (n == 0) return VO_OK;
     HIP_TRY(c, hipSetDevice(c->device));
-    const size_t in_b = (size_t)n * (mode == 0 ? 11 : 20) * 8, out_b = (size_t)n * (mode == 0 ? 20 : 91) * 8;
+    const size_t in_b = (size_t)n * (mode % 2 == 0 ? 11 : 20) * 8, out_b = (size_t)n * (mode % 2 == 0 ? 20 : 91) * 8;
     DevBuf d_in, d_out;   // a test hook: its buffers live for the call only
     ALLOC(c, d_in, in_b);
     int rc = dev_alloc(c, d_out, out_b);

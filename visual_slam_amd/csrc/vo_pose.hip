@@ -178,6 +178,9 @@ __device__ __forceinline__ Cx cdiv(Cx a, Cx b) {
 #ifndef DK_SWEEPS
 #define DK_SWEEPS 300  // cv::solvePoly's maxIters at the reference's call (timing experiments lower it)
 #endif
+#ifndef VO_WIDE_SOLVE_MAX_HYP
+#define VO_WIDE_SOLVE_MAX_HYP 2048   // hypotheses per round up to which the 16-lanes-per-hypothesis solver runs (measured crossover: 1.73 against 2.05 ms at 2048, 2.65 against 2.07 ms at 4096)
+#endif
 #ifndef DK_SWEEP_MODE
 #define DK_SWEEP_MODE 1   // 0: round 1's branchy root updates (A/B runs); 1: straight-line updates with a rare redo
 #endif
@@ -390,9 +393,109 @@ __device__ void solve_poly10(const double* coeffs_in, double* out_re, double* ou
     for (; n < 10; n++) { out_re[n] = out_re[n - 1]; out_im[n] = out_im[n - 1]; }
 }
 
+// ---- the same root finder spread over the 16 lanes of a DPP row, for calls with few hypotheses (one pair at a time):
+// lane k < 10 of the row owns root k, and every lane keeps a copy of all ten.  A sweep is then
+//   Horner numerators: ten lanes side by side;
+//   for i = 0..9: lane i multiplies the factors with the OLD roots j > i into its denominator, divides, and its new root is
+//     broadcast along the row (DPP row_newbcast: no LDS, no barrier); the lanes k > i multiply (p_k - new_i) into theirs.
+// Every chain's operations and their order are those of the one-lane sweep (new roots j < k ascending, then old roots
+// j > k ascending), so the roots are bit identical; about 1.1 k dependent instructions per sweep instead of 1.95 k.
+// All 16 lanes of a row must call it together with the same coefficients (rows are independent of each other).
+template <int I>
+__device__ __forceinline__ double row_bcast(double v) {
+    // row_newbcast:I; every lane reads an active lane of its own row, so bound_ctrl only saves the "old value" move
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), 0x150 + I, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), 0x150 + I, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+template <int CTRL>
+__device__ __forceinline__ double row_dpp(double v) {
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+// msq / bad are this lane's own step (|q|^2, denominator unusable); they are reduced over the row once per sweep
+template <int I>
+__device__ __forceinline__ void dkw_step(const int k, Cx& p, const Cx& num, Cx& den, double (&cre)[10], double (&cim)[10], double& msq, int& bad) {
+    Cx np_ = p;
+    if (k == I) {
+#pragma unroll
+        for (int j = I + 1; j < 10; j++) den = cmul(den, csub(p, Cx{cre[j], cim[j]}));
+        bad = ((den.re != 0 || den.im != 0) && den.re == den.re && den.im == den.im) ? 0 : 1;   // see dk_update_root_fast
+        const Cx q = cdiv(num, den);
+        np_ = Cx{p.re - q.re, p.im - q.im};
+        msq = q.re * q.re + q.im * q.im;
+        p = np_;
+    }
+    const double nre = row_bcast<I>(np_.re), nim = row_bcast<I>(np_.im);
+    cre[I] = nre; cim[I] = nim;
+    if (k > I) den = cmul(den, csub(p, Cx{nre, nim}));
+}
+
+__device__ void solve_poly10_wide(const double* coeffs_in, double* out_re, double* out_im, const int sub) {
+    int n = 10;
+    for (; n > 1; n--)
+        if (fabs(coeffs_in[n]) > DBL_EPSILON) break;
+    if (n != 10) { solve_poly10(coeffs_in, out_re, out_im); return; }   // lower degree: every lane for itself (identical results)
+    const int k = sub < 10 ? sub : 9;              // lanes 10..15 of the row shadow lane 9
+    double coef[11], cre[10], cim[10];
+#pragma unroll
+    for (int i = 0; i <= 10; i++) coef[i] = coeffs_in[i];
+    Cx p{1, 0};
+    {
+        Cx q{1, 0};
+        const Cx r{1, 1};
+#pragma unroll
+        for (int i = 0; i < 10; i++) {
+            cre[i] = q.re; cim[i] = q.im;
+            if (i == k) p = q;
+            q = cmul(q, r);
+        }
+    }
+    bool redo = false;
+    for (int iter = 0; iter < DK_SWEEPS; iter++) {
+        double msq = 0;
+        int bad = 0;
+        Cx num{coef[10], 0}, den{coef[10], 0};
+#pragma unroll
+        for (int j = 0; j < 10; j++) num = cadd(cmul(num, p), Cx{coef[9 - j], 0});
+        dkw_step<0>(k, p, num, den, cre, cim, msq, bad);
+        dkw_step<1>(k, p, num, den, cre, cim, msq, bad);
+        dkw_step<2>(k, p, num, den, cre, cim, msq, bad);
+        dkw_step<3>(k, p, num, den, cre, cim, msq, bad);
+        dkw_step<4>(k, p, num, den, cre, cim, msq, bad);
+        dkw_step<5>(k, p, num, den, cre, cim, msq, bad);
+        dkw_step<6>(k, p, num, den, cre, cim, msq, bad);
+        dkw_step<7>(k, p, num, den, cre, cim, msq, bad);
+        dkw_step<8>(k, p, num, den, cre, cim, msq, bad);
+        dkw_step<9>(k, p, num, den, cre, cim, msq, bad);
+        // row-wide "largest step > 0" and "some denominator unusable".  The one-lane loop tests fmax over the roots of |q|^2
+        // against 0, with fmax dropping NaNs: that is "some |q|^2 > 0".
+        int any = (msq > 0 ? 1 : 0) | (bad << 1);
+        any |= __builtin_amdgcn_mov_dpp(any, 0x121, 0xf, 0xf, true);   // row_ror:1
+        any |= __builtin_amdgcn_mov_dpp(any, 0x122, 0xf, 0xf, true);   // row_ror:2
+        any |= __builtin_amdgcn_mov_dpp(any, 0x124, 0xf, 0xf, true);   // row_ror:4
+        any |= __builtin_amdgcn_mov_dpp(any, 0x128, 0xf, 0xf, true);   // row_ror:8
+        if (__builtin_expect(any & 2, 0)) { redo = true; break; }
+        if (!(any & 1)) break;
+    }
+    if (redo) {
+        // a denominator came out zero or NaN somewhere (coincident iterates, over/underflow): every lane solves the polynomial
+        // again by itself with the one-lane code, which handles those cases root by root
+        solve_poly10(coeffs_in, out_re, out_im);
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < 10; i++) { out_re[i] = cre[i]; out_im[i] = cim[i]; }
+    for (int i = 0; i < 10; i++)
+        if (fabs(out_im[i]) < 1e-100) out_im[i] = 0;
+}
+
 // EMEstimatorCallback::runKernel.  x1,x2: 5 normalised correspondences.  Writes up to 10
 // models (row-major, unit Frobenius norm, x2^T E x1 = 0) to Ebuf; returns their number.
-__device__ int five_point(const double* x1, const double* x2, double* Ebuf) {
+// sub < 0: one lane per call.  sub = 0..15: the 16 lanes of a DPP row call it together with the same correspondences (the root
+// finder is shared among them, everything else is computed by each lane for itself with identical results).
+__device__ int five_point(const double* x1, const double* x2, double* Ebuf, const int sub = -1) {
     double At[9 * 9];
     for (int i = 0; i < 81; i++) At[i] = 0;
     for (int i = 0; i < 5; i++) {
@@ -509,7 +612,8 @@ __device__ int five_point(const double* x1, const double* x2, double* Ebuf) {
         for (int k = 0; k <= 10; k++) cdet[k] += sgn * term[k];
     }
     double rre[10], rim[10];
-    solve_poly10(cdet, rre, rim);
+    if (sub < 0) solve_poly10(cdet, rre, rim);
+    else solve_poly10_wide(cdet, rre, rim, sub);
     int count = 0;
     for (int i = 0; i < 10; i++) {
         if (fabs(rim[i]) > 1e-10) continue;
@@ -633,6 +737,33 @@ __global__ __launch_bounds__(DK_T) void k_ransac_solve(const PoseWork* __restric
     }
     double Eb[90];
     const int nm = five_point(x1, x2, Eb);
+    nmodels[ho] = nm;
+    double* mo = models + ho * 90;
+    for (int i = 0; i < nm * 9; i++) mo[i] = Eb[i];
+}
+
+// The same with 16 lanes (one DPP row) per hypothesis, for rounds with few hypotheses in total: the serial chain of a
+// hypothesis is shorter (solve_poly10_wide), at 16 times the lanes.  Bit-identical models.
+__global__ __launch_bounds__(DK_T) void k_ransac_solve_wide(const PoseWork* __restrict__ pw, const int* __restrict__ nmatch, int P, int nh, int kp_cap,
+                                                            const float2* __restrict__ q1, const float2* __restrict__ q2, NormK nk,
+                                                            const int* __restrict__ samples, double* __restrict__ models, int* __restrict__ nmodels) {
+    const int g = (blockIdx.x * DK_T + threadIdx.x) >> 4, sub = threadIdx.x & 15;
+    const int p = g / nh, h = g % nh;
+    if (p >= P) return;                                        // row-uniform exits
+    const PoseWork& w = pw[p];
+    if (w.done) return;
+    const long ho = (long)p * VO_HYP_ROUND + h;
+    if (w.iter + h >= w.niters) { if (sub == 0) nmodels[ho] = 0; return; }
+    const int* sp = samples + ho * 5;
+    double x1[10], x2[10];
+    for (int i = 0; i < 5; i++) {
+        const long o = (long)p * kp_cap + sp[i];
+        norm_pt(nk, q1[o], x1[2 * i], x1[2 * i + 1]);
+        norm_pt(nk, q2[o], x2[2 * i], x2[2 * i + 1]);
+    }
+    double Eb[90];
+    const int nm = five_point(x1, x2, Eb, sub);
+    if (sub != 0) return;
     nmodels[ho] = nm;
     double* mo = models + ho * 90;
     for (int i = 0; i < nm * 9; i++) mo[i] = Eb[i];
@@ -903,7 +1034,11 @@ int vo_launch_ransac(vo_ctx* c, int P, const double K[9], double prob, double th
         const int nh = round == 0 ? first_round : VO_HYP_ROUND;
         if (!host_free) HIP_TRY(c, hipMemsetAsync(active, 0, sizeof(int), st));
         hipLaunchKernelGGL(k_ransac_sample, dim3(pb), dim3(64), 0, st, pw, nmatch, P, nh, samples);
-        hipLaunchKernelGGL(k_ransac_solve, dim3((P * nh + DK_T - 1) / DK_T), dim3(DK_T), 0, st, pw, nmatch, P, nh, kp_cap, q1, q2, nk, samples, models, nmodels);
+        // few hypotheses in the round (single pairs, small batches): a DPP row per hypothesis, one wavefront per SIMD at most
+        if ((long)P * nh <= VO_WIDE_SOLVE_MAX_HYP)
+            hipLaunchKernelGGL(k_ransac_solve_wide, dim3((P * nh * 16 + DK_T - 1) / DK_T), dim3(DK_T), 0, st, pw, nmatch, P, nh, kp_cap, q1, q2, nk, samples, models, nmodels);
+        else
+            hipLaunchKernelGGL(k_ransac_solve, dim3((P * nh + DK_T - 1) / DK_T), dim3(DK_T), 0, st, pw, nmatch, P, nh, kp_cap, q1, q2, nk, samples, models, nmodels);
         hipLaunchKernelGGL(k_ransac_score, dim3((nh + 3) / 4, P), dim3(256), 0, st, pw, nmatch, P, nh, kp_cap, q1, q2, nk, thr2, models, nmodels, counts);
         hipLaunchKernelGGL(k_ransac_scan, dim3(pb), dim3(64), 0, st, pw, nmatch, P, nh, prob, models, nmodels, counts, host_free ? nullptr : active);
         iters_done += nh;
@@ -940,9 +1075,25 @@ int vo_launch_recover(vo_ctx* c, int P, const double K[9], double dist_thresh, h
 // mode 0: in = 11 coefficients (ascending powers), out = 10 roots as (re, im) pairs
 // mode 1: in = x1[5][2], x2[5][2] (normalised points), out = model count followed by 10 row-major E
 __global__ __launch_bounds__(DK_T) void k_debug_minimal(int mode, const double* __restrict__ in, int n, double* __restrict__ out) {
-    const int t = blockIdx.x * DK_T + threadIdx.x;
+    const bool wide = mode >= 2;                 // modes 2, 3: 16 lanes (a DPP row) per case
+    const int t = wide ? (blockIdx.x * DK_T + threadIdx.x) >> 4 : blockIdx.x * DK_T + threadIdx.x;
+    const int sub = wide ? (int)(threadIdx.x & 15) : -1;
     if (t >= n) return;
-    if (mode == 0) {
+    if (mode == 2) {
+        double c[11], re[10], im[10];
+        for (int i = 0; i < 11; i++) c[i] = in[(size_t)t * 11 + i];
+        solve_poly10_wide(c, re, im, sub);
+        if (sub == 0) for (int i = 0; i < 10; i++) { out[(size_t)t * 20 + 2 * i] = re[i]; out[(size_t)t * 20 + 2 * i + 1] = im[i]; }
+    } else if (mode == 3) {
+        double x1[10], x2[10], Eb[90];
+        for (int i = 0; i < 10; i++) { x1[i] = in[(size_t)t * 20 + i]; x2[i] = in[(size_t)t * 20 + 10 + i]; }
+        for (int i = 0; i < 90; i++) Eb[i] = 0;
+        const int nm = five_point(x1, x2, Eb, sub);
+        if (sub == 0) {
+            out[(size_t)t * 91] = nm;
+            for (int i = 0; i < 90; i++) out[(size_t)t * 91 + 1 + i] = i < 9 * nm ? Eb[i] : 0.0;
+        }
+    } else if (mode == 0) {
         double c[11], re[10], im[10];
         for (int i = 0; i < 11; i++) c[i] = in[(size_t)t * 11 + i];
         solve_poly10(c, re, im);
@@ -957,7 +1108,8 @@ __global__ __launch_bounds__(DK_T) void k_debug_minimal(int mode, const double* 
     }
 }
 int vo_launch_debug_minimal(vo_ctx* c, int mode, const double* d_in, int n, double* d_out, hipStream_t st) {
-    hipLaunchKernelGGL(k_debug_minimal, dim3((n + DK_T - 1) / DK_T), dim3(DK_T), 0, st, mode, d_in, n, d_out);
+    const long lanes = mode >= 2 ? (long)n * 16 : n;
+    hipLaunchKernelGGL(k_debug_minimal, dim3((unsigned)((lanes + DK_T - 1) / DK_T)), dim3(DK_T), 0, st, mode, d_in, n, d_out);
     HIP_TRY(c, hipGetLastError());
     return VO_OK;
 }
