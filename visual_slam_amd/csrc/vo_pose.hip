@@ -141,9 +141,10 @@ __device__ void svd_square(const double* A, double* W, double* U, double* Vt) {
 }
 
 // ------------------------------------------------------------------ polynomials in (x,y,z), degree <= 3
+// c[i][j][k] multiplies x^i y^j z^k; only the 20 entries with i + j + k <= 3 exist (the others are never written or read)
 struct Poly3 { double c[4][4][4]; };
 __device__ void pzero(Poly3& r) {
-    for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) for (int k = 0; k < 4; k++) r.c[i][j][k] = 0;
+    for (int i = 0; i < 4; i++) for (int j = 0; i + j < 4; j++) for (int k = 0; i + j + k < 4; k++) r.c[i][j][k] = 0;
 }
 // r = a*b (degrees da, db)
 __device__ void pmul(Poly3& r, const Poly3& a, int da, const Poly3& b, int db) {
@@ -160,7 +161,7 @@ __device__ void pmul(Poly3& r, const Poly3& a, int da, const Poly3& b, int db) {
 }
 // r = a + sb*b
 __device__ void padd(Poly3& r, const Poly3& a, const Poly3& b, double sb) {
-    for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) for (int k = 0; k < 4; k++) r.c[i][j][k] = a.c[i][j][k] + sb * b.c[i][j][k];
+    for (int i = 0; i < 4; i++) for (int j = 0; i + j < 4; j++) for (int k = 0; i + j + k < 4; k++) r.c[i][j][k] = a.c[i][j][k] + sb * b.c[i][j][k];
 }
 __constant__ signed char c_mono[20][3] = {{3, 0, 0}, {0, 3, 0}, {2, 1, 0}, {1, 2, 0}, {2, 0, 1}, {2, 0, 0}, {0, 2, 1}, {0, 2, 0}, {1, 1, 1}, {1, 1, 0},
                                           {1, 0, 2}, {1, 0, 1}, {1, 0, 0}, {0, 1, 2}, {0, 1, 1}, {0, 1, 0}, {0, 0, 3}, {0, 0, 2}, {0, 0, 1}, {0, 0, 0}};
@@ -180,6 +181,15 @@ __device__ __forceinline__ Cx cdiv(Cx a, Cx b) {
 #endif
 #ifndef VO_WIDE_SOLVE_MAX_HYP
 #define VO_WIDE_SOLVE_MAX_HYP 2048   // hypotheses per round up to which the 16-lanes-per-hypothesis solver runs (measured crossover: 1.73 against 2.05 ms at 2048, 2.65 against 2.07 ms at 4096)
+#endif
+// -DFP_CLOCKS (experiment builds, tools/exp_solver_clocks.py): the solver stamps the cycle counter at its phase boundaries into
+// the unused tail of the model buffer, which the debug hook then returns
+#ifdef FP_CLOCKS
+#define FP_CLOCKS_ON 1
+#define FP_TICK(i) Ebuf[80 + (i)] = (double)__builtin_readcyclecounter()
+#else
+#define FP_CLOCKS_ON 0
+#define FP_TICK(i)
 #endif
 #ifndef DK_SWEEP_MODE
 #define DK_SWEEP_MODE 1   // 0: round 1's branchy root updates (A/B runs); 1: straight-line updates with a rare redo
@@ -496,6 +506,7 @@ __device__ void solve_poly10_wide(const double* coeffs_in, double* out_re, doubl
 // sub < 0: one lane per call.  sub = 0..15: the 16 lanes of a DPP row call it together with the same correspondences (the root
 // finder is shared among them, everything else is computed by each lane for itself with identical results).
 __device__ int five_point(const double* x1, const double* x2, double* Ebuf, const int sub = -1) {
+    FP_TICK(0);
     double At[9 * 9];
     for (int i = 0; i < 81; i++) At[i] = 0;
     for (int i = 0; i < 5; i++) {
@@ -508,6 +519,7 @@ __device__ int five_point(const double* x1, const double* x2, double* Ebuf, cons
     double W[5], V[25];
     jacobi_svd<9, 5, 9>(At, W, V);
     const double* EE0 = At + 5 * 9;  // 4 null-space vectors, consecutive rows
+    FP_TICK(1);
 
     Poly3 Ep[3][3];
     for (int r = 0; r < 3; r++)
@@ -558,23 +570,61 @@ __device__ int five_point(const double* x1, const double* x2, double* Ebuf, cons
             padd(s, s, tmp, -1.0);
             store_eq(1 + r * 3 + c, s);
         }
+    FP_TICK(2);
+    // Gauss-Jordan with partial pivoting.  A lives in private memory, where a dependent access costs a round trip of several
+    // hundred cycles, and the loop as OpenCV writes it is one such round trip per element (300 us of the solver's 420 us outside the
+    // root finder).  Here every loop bound is a compile-time constant after unrolling (only the pivot row's index is data) and a
+    // column step is five batches of independent loads: the column, the pivot row and row `col`, then the other nine rows three at
+    // a time.  The arithmetic per element is unchanged; "skip the row if f == 0" is a select (f * pr could be NaN or change a
+    // zero's sign); columns left of `col` are not touched (they are never read again).
+#pragma unroll
     for (int col = 0; col < 10; col++) {
+        double cv[10];
+#pragma unroll
+        for (int r = 0; r < 10; r++) cv[r] = A[r][col];
         int piv = col;
-        double best = fabs(A[col][col]);
-        for (int r = col + 1; r < 10; r++)
-            if (fabs(A[r][col]) > best) { best = fabs(A[r][col]); piv = r; }
+        double best = fabs(cv[col]);
+#pragma unroll
+        for (int r = col + 1; r < 10; r++) {
+            const double v = fabs(cv[r]);
+            if (v > best) { best = v; piv = r; }
+        }
         if (best < DBL_MIN) return 0;
-        if (piv != col)
-            for (int m = 0; m < 20; m++) { double t = A[piv][m]; A[piv][m] = A[col][m]; A[col][m] = t; }
-        const double inv = 1.0 / A[col][col];
-        for (int m = col; m < 20; m++) A[col][m] *= inv;
-        for (int r = 0; r < 10; r++) {
-            if (r == col) continue;
-            const double f = A[r][col];
-            if (f == 0) continue;
-            for (int m = col; m < 20; m++) A[r][m] -= f * A[col][m];
+        double pr[20], oc[20];
+#pragma unroll
+        for (int m = col; m < 20; m++) { pr[m] = A[piv][m]; oc[m] = A[col][m]; }
+#pragma unroll
+        for (int m = col; m < 20; m++) A[piv][m] = oc[m];          // the swap (a plain rewrite when piv == col)
+        const double inv = 1.0 / pr[col];
+#pragma unroll
+        for (int m = col; m < 20; m++) { pr[m] *= inv; A[col][m] = pr[m]; }
+#pragma unroll
+        for (int r0 = 0; r0 < 10; r0 += 3) {
+            double row[3][20];
+#pragma unroll
+            for (int q = 0; q < 3; q++) {
+                const int r = r0 + q;
+                if (r < 10 && r != col) {
+#pragma unroll
+                    for (int m = col; m < 20; m++) row[q][m] = A[r][m];
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 3; q++) {
+                const int r = r0 + q;
+                if (r < 10 && r != col) {
+                    const double f = (r > col && r == piv) ? cv[col] : cv[r];   // row piv now holds what row col held
+                    const bool skip = f == 0;
+#pragma unroll
+                    for (int m = col; m < 20; m++) {
+                        const double t = row[q][m] - f * pr[m];
+                        A[r][m] = skip ? row[q][m] : t;
+                    }
+                }
+            }
         }
     }
+    FP_TICK(3);
     double b[3][13];
     for (int i = 0; i < 3; i++) {
         const double* a1 = &A[i * 2 + 4][10];
@@ -611,9 +661,11 @@ __device__ int five_point(const double* x1, const double* x2, double* Ebuf, cons
         const double sgn = (r == 1) ? -1.0 : 1.0;
         for (int k = 0; k <= 10; k++) cdet[k] += sgn * term[k];
     }
+    FP_TICK(4);
     double rre[10], rim[10];
     if (sub < 0) solve_poly10(cdet, rre, rim);
     else solve_poly10_wide(cdet, rre, rim, sub);
+    FP_TICK(5);
     int count = 0;
     for (int i = 0; i < 10; i++) {
         if (fabs(rim[i]) > 1e-10) continue;
@@ -640,6 +692,7 @@ __device__ int five_point(const double* x1, const double* x2, double* Ebuf, cons
         for (int k = 0; k < 9; k++) E[k] /= nrm;
         count++;
     }
+    FP_TICK(6);
     return count;
 }
 
@@ -1091,7 +1144,7 @@ __global__ __launch_bounds__(DK_T) void k_debug_minimal(int mode, const double* 
         const int nm = five_point(x1, x2, Eb, sub);
         if (sub == 0) {
             out[(size_t)t * 91] = nm;
-            for (int i = 0; i < 90; i++) out[(size_t)t * 91 + 1 + i] = i < 9 * nm ? Eb[i] : 0.0;
+            for (int i = 0; i < 90; i++) out[(size_t)t * 91 + 1 + i] = (i < 9 * nm || (FP_CLOCKS_ON && i >= 80)) ? Eb[i] : 0.0;
         }
     } else if (mode == 0) {
         double c[11], re[10], im[10];
@@ -1104,7 +1157,7 @@ __global__ __launch_bounds__(DK_T) void k_debug_minimal(int mode, const double* 
         for (int i = 0; i < 90; i++) Eb[i] = 0;
         const int nm = five_point(x1, x2, Eb);
         out[(size_t)t * 91] = nm;
-        for (int i = 0; i < 90; i++) out[(size_t)t * 91 + 1 + i] = i < 9 * nm ? Eb[i] : 0.0;
+        for (int i = 0; i < 90; i++) out[(size_t)t * 91 + 1 + i] = (i < 9 * nm || (FP_CLOCKS_ON && i >= 80)) ? Eb[i] : 0.0;
     }
 }
 int vo_launch_debug_minimal(vo_ctx* c, int mode, const double* d_in, int n, double* d_out, hipStream_t st) {
