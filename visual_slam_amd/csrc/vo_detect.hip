@@ -146,6 +146,10 @@ int vo_build_geometry(vo_ctx* c, int w, int h) {
         if (l > 0) {
             linear_coeffs(g.lv[l - 1].w, L.w, &c->h_rtab[L.xtab]);
             linear_coeffs(g.lv[l - 1].h, L.h, &c->h_rtab[L.ytab]);
+            // the tables are read four entries at a time: the padding repeats the last coefficient, so a lane never has to
+            // clamp an index (outputs past the level's edge are computed from it and masked out of the store)
+            for (long d = L.w; d < align_up(L.w, 4); d++) c->h_rtab[L.xtab + d] = c->h_rtab[L.xtab + L.w - 1];
+            for (long d = L.h; d < align_up(L.h, 4); d++) c->h_rtab[L.ytab + d] = c->h_rtab[L.ytab + L.h - 1];
         }
     }
     // workspace capacity check against what vo_ctx_create allocated (sized for max_w x max_h)
@@ -184,24 +188,27 @@ __global__ __launch_bounds__(256) void k_pyramid(const Geom* __restrict__ g, Fra
     int spitch;
     const uint8_t* sp = level_ptr(g, src, pyr, f, l - 1, spitch);
     const int sw = g->lv[l - 1].w, sh = g->lv[l - 1].h;
-    const uint4 cx4 = *reinterpret_cast<const uint4*>(rt + L.xtab + x4);
+    // coefficient tables: 32-bit offsets from a uniform base, four entries per load (the tables' padding repeats the last entry)
+    const ResizeCoef* const xt = rt + L.xtab;
+    const ResizeCoef* const yt = rt + L.ytab;
+    const uint4 cx4 = *reinterpret_cast<const uint4*>(xt + (uint32_t)x4);
+    const uint4 cy4 = *reinterpret_cast<const uint4*>(yt + (uint32_t)y0);
     const uint32_t cx[4] = {cx4.x, cx4.y, cx4.z, cx4.w};
     const int nvalid = min(4, L.w - x4);
     const int o0 = (int)(cx[0] & 0xFFFF);
-    const int olast = (int)(cx[nvalid - 1] & 0xFFFF);
+    const int olast = (int)(cx[3] & 0xFFFF);
     uint8_t* const lbase = pyr + (long)f * g->pyr_frame + L.pyr_ofs;             // uniform
     const uint32_t dofs = (uint32_t)y0 * (uint32_t)L.pitch + (uint32_t)x4;
-    uint32_t cyv[PYR_ROWS];
-#pragma unroll
-    for (int r = 0; r < PYR_ROWS; r++) cyv[r] = rt[L.ytab + min(y0 + r, L.h - 1)];
+    static_assert(PYR_ROWS == 4, "one uint4 of row coefficients per lane");
+    const uint32_t cyv[PYR_ROWS] = {cy4.x, cy4.y, cy4.z, cy4.w};
     if (olast + 1 - o0 < 8 && o0 + 8 <= sw) {
         uint2 a[PYR_ROWS], b[PYR_ROWS];
 #pragma unroll
         for (int r = 0; r < PYR_ROWS; r++) {
             // 32-bit lane offsets from the level's (uniform) base: no 64-bit multiply-adds per load
             const uint32_t oy = cyv[r] & 0xFFFF;
-            __builtin_memcpy(&a[r], sp + (oy * (uint32_t)spitch + (uint32_t)o0), 8);
-            __builtin_memcpy(&b[r], sp + (min(oy + 1u, (uint32_t)sh - 1u) * (uint32_t)spitch + (uint32_t)o0), 8);
+            __builtin_memcpy(&a[r], sp + (__umul24(oy, (uint32_t)spitch) + (uint32_t)o0), 8);        // rows and pitches are < 2^12
+            __builtin_memcpy(&b[r], sp + (__umul24(min(oy + 1u, (uint32_t)sh - 1u), (uint32_t)spitch) + (uint32_t)o0), 8);
         }
         // v_perm_b32 selectors placing source bytes (rel, rel+1) of the 8 loaded ones as a u16 pair, and the weight pair
         // c0 | c1 << 16 -- the same for all rows of the lane; H = c0*p[i] + c1*p[i+1] is then one v_dot2_u32_u16, and
@@ -209,9 +216,9 @@ __global__ __launch_bounds__(256) void k_pyramid(const Geom* __restrict__ g, Fra
         uint32_t sel[4], cxp[4];
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            const uint32_t rel = (cx[min(i, nvalid - 1)] & 0xFFFF) - (uint32_t)o0;
+            const uint32_t rel = (cx[i] & 0xFFFF) - (uint32_t)o0;
             sel[i] = 0x0C010C00u + rel * 0x00010001u;
-            cxp[i] = 256u + (cx[min(i, nvalid - 1)] >> 16) * 65535u;
+            cxp[i] = 256u + (cx[i] >> 16) * 65535u;
         }
 #pragma unroll
         for (int r = 0; r < PYR_ROWS; r++) {
