@@ -517,6 +517,7 @@ __global__ __launch_bounds__(256) void k_fast_tiles(const Geom* __restrict__ g, 
 // along both axes in LDS.  (Round 1 ran a scan kernel per level between k_fast_tiles and a per-tile emit kernel.)
 // The workgroup of a level's last tile row also writes the level's total.
 #define EM_MAXX 72   // tile columns: (4095 - 62) / 60 rounded up is 68
+static_assert((4095 - 2 * VO_EDGE + VO_TILE_W - 1) / VO_TILE_W <= EM_MAXX && VO_TILE_H <= 32 && VO_TILE_CAP < 65536, "k_fast_emit LDS tables (vo_build_geometry accepts widths up to 4095)");
 __global__ __launch_bounds__(256) void k_fast_emit(const Geom* __restrict__ g, const uint32_t* __restrict__ tile_list,
                                                    const uint8_t* __restrict__ seg_cnt, const uint32_t* __restrict__ tile_cnt,
                                                    int* __restrict__ cnt_fast, float* __restrict__ key, uint32_t* __restrict__ payload,
