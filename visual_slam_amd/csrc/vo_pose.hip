@@ -501,10 +501,33 @@ __device__ void solve_poly10_wide(const double* coeffs_in, double* out_re, doubl
         if (fabs(out_im[i]) < 1e-100) out_im[i] = 0;
 }
 
+// ---- row-wide helpers for the 16-lanes-per-hypothesis solver (all 16 lanes of a DPP row active)
+template <int N> __device__ __forceinline__ int row_ror(int v) { return __builtin_amdgcn_mov_dpp(v, 0x120 + N, 0xf, 0xf, true); }
+template <int N> __device__ __forceinline__ double row_ror(double v) { return row_dpp<0x120 + N>(v); }
+// the smallest value of the row, in every lane
+__device__ __forceinline__ int row_min(int v) {
+    v = min(v, row_ror<1>(v)); v = min(v, row_ror<2>(v)); v = min(v, row_ror<4>(v)); v = min(v, row_ror<8>(v));
+    return v;
+}
+__device__ __forceinline__ int row_or(int v) {
+    v |= row_ror<1>(v); v |= row_ror<2>(v); v |= row_ror<4>(v); v |= row_ror<8>(v);
+    return v;
+}
+// v of lane `src` (a lane index in the wavefront, the same in every lane of the row)
+__device__ __forceinline__ double lane_read(int src, double v) {
+    const int lo = __builtin_amdgcn_ds_bpermute(src << 2, __double2loint(v));
+    const int hi = __builtin_amdgcn_ds_bpermute(src << 2, __double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+
 // EMEstimatorCallback::runKernel.  x1,x2: 5 normalised correspondences.  Writes up to 10
 // models (row-major, unit Frobenius norm, x2^T E x1 = 0) to Ebuf; returns their number.
-// sub < 0: one lane per call.  sub = 0..15: the 16 lanes of a DPP row call it together with the same correspondences (the root
-// finder is shared among them, everything else is computed by each lane for itself with identical results).
+// WIDE = false: one lane per call (sub is ignored).  WIDE = true: the 16 lanes of a DPP row call it together with the same
+// correspondences, sub = 0..15 the lane's place in the row: the null space and E E^T are computed by every lane for itself
+// (identical results), and then lane k owns constraint k -- it expands that equation, holds that matrix row through the
+// elimination (pivot search and pivot row travel along the row by DPP / ds_bpermute), owns root k of the tenth-degree polynomial
+// and back-substitutes it.  Every number is produced by the same operations in the same order as in the one-lane form.
+template <bool WIDE>
 __device__ int five_point(const double* x1, const double* x2, double* Ebuf, const int sub = -1) {
     FP_TICK(0);
     double At[9 * 9];
@@ -544,91 +567,167 @@ __device__ int five_point(const double* x1, const double* x2, double* Ebuf, cons
     Poly3 tr;
     padd(tr, EEt[0][0], EEt[1][1], 1.0);
     padd(tr, tr, EEt[2][2], 1.0);
-    double A[10][20];
-    auto store_eq = [&](int e, const Poly3& q) {
-        for (int m = 0; m < 20; m++) A[e][m] = q.c[c_mono[m][0]][c_mono[m][1]][c_mono[m][2]];
-    };
-    {
-        Poly3 m0, m1, m2, d;
-        pmul(tmp, Ep[1][1], 1, Ep[2][2], 1); pmul(tmp2, Ep[1][2], 1, Ep[2][1], 1); padd(m0, tmp, tmp2, -1.0);
-        pmul(tmp, Ep[1][0], 1, Ep[2][2], 1); pmul(tmp2, Ep[1][2], 1, Ep[2][0], 1); padd(m1, tmp, tmp2, -1.0);
-        pmul(tmp, Ep[1][0], 1, Ep[2][1], 1); pmul(tmp2, Ep[1][1], 1, Ep[2][0], 1); padd(m2, tmp, tmp2, -1.0);
-        pmul(d, Ep[0][0], 1, m0, 2);
-        pmul(tmp, Ep[0][1], 1, m1, 2); padd(d, d, tmp, -1.0);
-        pmul(tmp, Ep[0][2], 1, m2, 2); padd(d, d, tmp, 1.0);
-        store_eq(0, d);
-    }
-    for (int r = 0; r < 3; r++)
-        for (int c = 0; c < 3; c++) {
-            Poly3 s;
-            pzero(s);
-            for (int k = 0; k < 3; k++) {
-                pmul(tmp, EEt[r][k], 2, Ep[k][c], 1);
-                padd(s, s, tmp, 2.0);
-            }
-            pmul(tmp, tr, 2, Ep[r][c], 1);
-            padd(s, s, tmp, -1.0);
-            store_eq(1 + r * 3 + c, s);
+    double A[10][20];          // one-lane form: the 10 x 20 constraint matrix
+    double Afin[6][10];        // 16-lane form: rows 4..9, columns 10..19 after the elimination (all that is read afterwards)
+    if (!WIDE) {
+        auto store_eq = [&](int e, const Poly3& q) {
+            for (int m = 0; m < 20; m++) A[e][m] = q.c[c_mono[m][0]][c_mono[m][1]][c_mono[m][2]];
+        };
+        {
+            Poly3 m0, m1, m2, d;
+            pmul(tmp, Ep[1][1], 1, Ep[2][2], 1); pmul(tmp2, Ep[1][2], 1, Ep[2][1], 1); padd(m0, tmp, tmp2, -1.0);
+            pmul(tmp, Ep[1][0], 1, Ep[2][2], 1); pmul(tmp2, Ep[1][2], 1, Ep[2][0], 1); padd(m1, tmp, tmp2, -1.0);
+            pmul(tmp, Ep[1][0], 1, Ep[2][1], 1); pmul(tmp2, Ep[1][1], 1, Ep[2][0], 1); padd(m2, tmp, tmp2, -1.0);
+            pmul(d, Ep[0][0], 1, m0, 2);
+            pmul(tmp, Ep[0][1], 1, m1, 2); padd(d, d, tmp, -1.0);
+            pmul(tmp, Ep[0][2], 1, m2, 2); padd(d, d, tmp, 1.0);
+            store_eq(0, d);
         }
-    FP_TICK(2);
-    // Gauss-Jordan with partial pivoting.  A lives in private memory, where a dependent access costs a round trip of several
-    // hundred cycles, and the loop as OpenCV writes it is one such round trip per element (300 us of the solver's 420 us outside the
-    // root finder).  Here every loop bound is a compile-time constant after unrolling (only the pivot row's index is data) and a
-    // column step is five batches of independent loads: the column, the pivot row and row `col`, then the other nine rows three at
-    // a time.  The arithmetic per element is unchanged; "skip the row if f == 0" is a select (f * pr could be NaN or change a
-    // zero's sign); columns left of `col` are not touched (they are never read again).
-#pragma unroll
-    for (int col = 0; col < 10; col++) {
-        double cv[10];
-#pragma unroll
-        for (int r = 0; r < 10; r++) cv[r] = A[r][col];
-        int piv = col;
-        double best = fabs(cv[col]);
-#pragma unroll
-        for (int r = col + 1; r < 10; r++) {
-            const double v = fabs(cv[r]);
-            if (v > best) { best = v; piv = r; }
-        }
-        if (best < DBL_MIN) return 0;
-        double pr[20], oc[20];
-#pragma unroll
-        for (int m = col; m < 20; m++) { pr[m] = A[piv][m]; oc[m] = A[col][m]; }
-#pragma unroll
-        for (int m = col; m < 20; m++) A[piv][m] = oc[m];          // the swap (a plain rewrite when piv == col)
-        const double inv = 1.0 / pr[col];
-#pragma unroll
-        for (int m = col; m < 20; m++) { pr[m] *= inv; A[col][m] = pr[m]; }
-#pragma unroll
-        for (int r0 = 0; r0 < 10; r0 += 3) {
-            double row[3][20];
-#pragma unroll
-            for (int q = 0; q < 3; q++) {
-                const int r = r0 + q;
-                if (r < 10 && r != col) {
-#pragma unroll
-                    for (int m = col; m < 20; m++) row[q][m] = A[r][m];
+        for (int r = 0; r < 3; r++)
+            for (int c = 0; c < 3; c++) {
+                Poly3 s;
+                pzero(s);
+                for (int k = 0; k < 3; k++) {
+                    pmul(tmp, EEt[r][k], 2, Ep[k][c], 1);
+                    padd(s, s, tmp, 2.0);
                 }
+                pmul(tmp, tr, 2, Ep[r][c], 1);
+                padd(s, s, tmp, -1.0);
+                store_eq(1 + r * 3 + c, s);
             }
-#pragma unroll
-            for (int q = 0; q < 3; q++) {
-                const int r = r0 + q;
-                if (r < 10 && r != col) {
-                    const double f = (r > col && r == piv) ? cv[col] : cv[r];   // row piv now holds what row col held
-                    const bool skip = f == 0;
-#pragma unroll
-                    for (int m = col; m < 20; m++) {
-                        const double t = row[q][m] - f * pr[m];
-                        A[r][m] = skip ? row[q][m] : t;
+        FP_TICK(2);
+        // Gauss-Jordan with partial pivoting.  A lives in private memory, where a dependent access costs a round trip of several
+        // hundred cycles, and the loop as OpenCV writes it is one such round trip per element (300 us of the solver's 420 us outside the
+        // root finder).  Here every loop bound is a compile-time constant after unrolling (only the pivot row's index is data) and a
+        // column step is five batches of independent loads: the column, the pivot row and row `col`, then the other nine rows three at
+        // a time.  The arithmetic per element is unchanged; "skip the row if f == 0" is a select (f * pr could be NaN or change a
+        // zero's sign); columns left of `col` are not touched (they are never read again).
+    #pragma unroll
+        for (int col = 0; col < 10; col++) {
+            double cv[10];
+    #pragma unroll
+            for (int r = 0; r < 10; r++) cv[r] = A[r][col];
+            int piv = col;
+            double best = fabs(cv[col]);
+    #pragma unroll
+            for (int r = col + 1; r < 10; r++) {
+                const double v = fabs(cv[r]);
+                if (v > best) { best = v; piv = r; }
+            }
+            if (best < DBL_MIN) return 0;
+            double pr[20], oc[20];
+    #pragma unroll
+            for (int m = col; m < 20; m++) { pr[m] = A[piv][m]; oc[m] = A[col][m]; }
+    #pragma unroll
+            for (int m = col; m < 20; m++) A[piv][m] = oc[m];          // the swap (a plain rewrite when piv == col)
+            const double inv = 1.0 / pr[col];
+    #pragma unroll
+            for (int m = col; m < 20; m++) { pr[m] *= inv; A[col][m] = pr[m]; }
+    #pragma unroll
+            for (int r0 = 0; r0 < 10; r0 += 3) {
+                double row[3][20];
+    #pragma unroll
+                for (int q = 0; q < 3; q++) {
+                    const int r = r0 + q;
+                    if (r < 10 && r != col) {
+    #pragma unroll
+                        for (int m = col; m < 20; m++) row[q][m] = A[r][m];
+                    }
+                }
+    #pragma unroll
+                for (int q = 0; q < 3; q++) {
+                    const int r = r0 + q;
+                    if (r < 10 && r != col) {
+                        const double f = (r > col && r == piv) ? cv[col] : cv[r];   // row piv now holds what row col held
+                        const bool skip = f == 0;
+    #pragma unroll
+                        for (int m = col; m < 20; m++) {
+                            const double t = row[q][m] - f * pr[m];
+                            A[r][m] = skip ? row[q][m] : t;
+                        }
                     }
                 }
             }
+        }
+    } else {
+        const int k = sub < 10 ? sub : 9;          // lanes 10..15 shadow lane 9
+        double row[20];
+        {
+            Poly3 q;
+            if (k == 0) {
+                Poly3 m0, m1, m2;
+                pmul(tmp, Ep[1][1], 1, Ep[2][2], 1); pmul(tmp2, Ep[1][2], 1, Ep[2][1], 1); padd(m0, tmp, tmp2, -1.0);
+                pmul(tmp, Ep[1][0], 1, Ep[2][2], 1); pmul(tmp2, Ep[1][2], 1, Ep[2][0], 1); padd(m1, tmp, tmp2, -1.0);
+                pmul(tmp, Ep[1][0], 1, Ep[2][1], 1); pmul(tmp2, Ep[1][1], 1, Ep[2][0], 1); padd(m2, tmp, tmp2, -1.0);
+                pmul(q, Ep[0][0], 1, m0, 2);
+                pmul(tmp, Ep[0][1], 1, m1, 2); padd(q, q, tmp, -1.0);
+                pmul(tmp, Ep[0][2], 1, m2, 2); padd(q, q, tmp, 1.0);
+            } else {
+                const int r = (k - 1) / 3, c = (k - 1) - 3 * r;
+                pzero(q);
+                for (int kk = 0; kk < 3; kk++) {
+                    pmul(tmp, EEt[r][kk], 2, Ep[kk][c], 1);
+                    padd(q, q, tmp, 2.0);
+                }
+                pmul(tmp, tr, 2, Ep[r][c], 1);
+                padd(q, q, tmp, -1.0);
+            }
+#pragma unroll
+            for (int m = 0; m < 20; m++) row[m] = q.c[c_mono[m][0]][c_mono[m][1]][c_mono[m][2]];
+        }
+        FP_TICK(2);
+        // Gauss-Jordan with the matrix row `lid` in this lane (a row swap exchanges the two lanes' lids, not their data)
+        int lid = k;
+        const int me = (int)__lane_id();
+#pragma unroll
+        for (int col = 0; col < 10; col++) {
+            // pivot = the first row >= col with the largest |A[r][col]|, as the serial scan finds it (it never moves to a NaN,
+            // and never away from a NaN in row col)
+            const double a = fabs(row[col]);
+            double best = (lid >= col && a == a) ? a : -1.0;
+            int piv = lid;
+#define VO_ARGMAX_STEP(N)                                                                         \
+            {                                                                                     \
+                const double ov = row_ror<N>(best);                                               \
+                const int oi = row_ror<N>(piv);                                                   \
+                const bool take = ov > best || (ov == best && oi < piv);                          \
+                best = take ? ov : best;                                                          \
+                piv = take ? oi : piv;                                                            \
+            }
+            VO_ARGMAX_STEP(1) VO_ARGMAX_STEP(2) VO_ARGMAX_STEP(4) VO_ARGMAX_STEP(8)
+#undef VO_ARGMAX_STEP
+            const bool nan_at_col = row_or((lid == col && a != a) ? 1 : 0) != 0;
+            if (nan_at_col) piv = col;
+            else if (best < DBL_MIN) return 0;
+            const int src = row_min(lid == piv ? me : 127);
+            double pr[20];
+#pragma unroll
+            for (int m = col; m < 20; m++) pr[m] = lane_read(src, row[m]);
+            if (lid == col) lid = piv;
+            else if (lid == piv) lid = col;
+            const double inv = 1.0 / pr[col];
+#pragma unroll
+            for (int m = col; m < 20; m++) pr[m] *= inv;
+            const double f = row[col];
+            const bool is_pivot = lid == col, skip = f == 0;
+#pragma unroll
+            for (int m = col; m < 20; m++) {
+                const double t = row[m] - f * pr[m];
+                row[m] = is_pivot ? pr[m] : (skip ? row[m] : t);
+            }
+        }
+#pragma unroll
+        for (int e = 4; e < 10; e++) {
+            const int src = row_min(lid == e ? me : 127);
+#pragma unroll
+            for (int j = 0; j < 10; j++) Afin[e - 4][j] = lane_read(src, row[10 + j]);
         }
     }
     FP_TICK(3);
     double b[3][13];
     for (int i = 0; i < 3; i++) {
-        const double* a1 = &A[i * 2 + 4][10];
-        const double* a2 = &A[i * 2 + 5][10];
+        const double* a1 = WIDE ? &Afin[i * 2][0] : &A[i * 2 + 4][10];
+        const double* a2 = WIDE ? &Afin[i * 2 + 1][0] : &A[i * 2 + 5][10];
         double row1[13], row2[13];
         for (int k = 0; k < 13; k++) { row1[k] = 0; row2[k] = 0; }
         for (int k = 0; k < 3; k++) { row1[1 + k] = a1[k]; row1[5 + k] = a1[3 + k]; }
@@ -663,13 +762,14 @@ __device__ int five_point(const double* x1, const double* x2, double* Ebuf, cons
     }
     FP_TICK(4);
     double rre[10], rim[10];
-    if (sub < 0) solve_poly10(cdet, rre, rim);
+    if (!WIDE) solve_poly10(cdet, rre, rim);
     else solve_poly10_wide(cdet, rre, rim, sub);
     FP_TICK(5);
-    int count = 0;
-    for (int i = 0; i < 10; i++) {
-        if (fabs(rim[i]) > 1e-10) continue;
-        const double z1 = rre[i], z2 = z1 * z1, z3 = z2 * z1, z4 = z3 * z1;
+    // the model of one root: back-substitution through the 3x3 null space; false if the root is complex or the null vector has no
+    // finite dehomogenisation
+    auto model_of_root = [&](const double zre, const double zim, double* E) -> bool {
+        if (fabs(zim) > 1e-10) return false;
+        const double z1 = zre, z2 = z1 * z1, z3 = z2 * z1, z4 = z3 * z1;
         double bz[9];
         for (int j = 0; j < 3; j++) {
             const double* br = b[j];
@@ -680,9 +780,8 @@ __device__ int five_point(const double* x1, const double* x2, double* Ebuf, cons
         double w3[3], U3[9], Vt3[9];
         svd_square<3>(bz, w3, U3, Vt3);
         const double* xy1 = Vt3 + 6;
-        if (fabs(xy1[2]) < 1e-10) continue;
+        if (fabs(xy1[2]) < 1e-10) return false;
         const double xs = xy1[0] / xy1[2], ys = xy1[1] / xy1[2], zs = z1;
-        double* E = Ebuf + count * 9;
         double nrm = 0;
         for (int k = 0; k < 9; k++) {
             E[k] = EE0[0 * 9 + k] * xs + EE0[1 * 9 + k] * ys + EE0[2 * 9 + k] * zs + EE0[3 * 9 + k];
@@ -690,7 +789,26 @@ __device__ int five_point(const double* x1, const double* x2, double* Ebuf, cons
         }
         nrm = sqrt(nrm);
         for (int k = 0; k < 9; k++) E[k] /= nrm;
-        count++;
+        return true;
+    };
+    int count = 0;
+    if (!WIDE) {
+        for (int i = 0; i < 10; i++)
+            if (model_of_root(rre[i], rim[i], Ebuf + count * 9)) count++;
+    } else {
+        // 16 lanes: lane k < 10 takes root k, then the models are collected in root order along the row (lanes 10..15 shadow lane 9)
+        const int k = sub < 10 ? sub : 9;
+        double Em[9];
+        for (int j = 0; j < 9; j++) Em[j] = 0;
+        const int mine = model_of_root(rre[k], rim[k], Em) ? 1 : 0;
+#define FP_COLLECT(I)                                                                                       \
+        if (__builtin_amdgcn_mov_dpp(mine, 0x150 + I, 0xf, 0xf, true)) {                                    \
+            for (int j = 0; j < 9; j++) Ebuf[count * 9 + j] = row_bcast<I>(Em[j]);                          \
+            count++;                                                                                        \
+        }
+        FP_COLLECT(0) FP_COLLECT(1) FP_COLLECT(2) FP_COLLECT(3) FP_COLLECT(4)
+        FP_COLLECT(5) FP_COLLECT(6) FP_COLLECT(7) FP_COLLECT(8) FP_COLLECT(9)
+#undef FP_COLLECT
     }
     FP_TICK(6);
     return count;
@@ -789,7 +907,7 @@ __global__ __launch_bounds__(DK_T) void k_ransac_solve(const PoseWork* __restric
         norm_pt(nk, q2[o], x2[2 * i], x2[2 * i + 1]);
     }
     double Eb[90];
-    const int nm = five_point(x1, x2, Eb);
+    const int nm = five_point<false>(x1, x2, Eb);
     nmodels[ho] = nm;
     double* mo = models + ho * 90;
     for (int i = 0; i < nm * 9; i++) mo[i] = Eb[i];
@@ -815,7 +933,7 @@ __global__ __launch_bounds__(DK_T) void k_ransac_solve_wide(const PoseWork* __re
         norm_pt(nk, q2[o], x2[2 * i], x2[2 * i + 1]);
     }
     double Eb[90];
-    const int nm = five_point(x1, x2, Eb, sub);
+    const int nm = five_point<true>(x1, x2, Eb, sub);
     if (sub != 0) return;
     nmodels[ho] = nm;
     double* mo = models + ho * 90;
@@ -1141,7 +1259,7 @@ __global__ __launch_bounds__(DK_T) void k_debug_minimal(int mode, const double* 
         double x1[10], x2[10], Eb[90];
         for (int i = 0; i < 10; i++) { x1[i] = in[(size_t)t * 20 + i]; x2[i] = in[(size_t)t * 20 + 10 + i]; }
         for (int i = 0; i < 90; i++) Eb[i] = 0;
-        const int nm = five_point(x1, x2, Eb, sub);
+        const int nm = five_point<true>(x1, x2, Eb, sub);
         if (sub == 0) {
             out[(size_t)t * 91] = nm;
             for (int i = 0; i < 90; i++) out[(size_t)t * 91 + 1 + i] = (i < 9 * nm || (FP_CLOCKS_ON && i >= 80)) ? Eb[i] : 0.0;
@@ -1155,7 +1273,7 @@ __global__ __launch_bounds__(DK_T) void k_debug_minimal(int mode, const double* 
         double x1[10], x2[10], Eb[90];
         for (int i = 0; i < 10; i++) { x1[i] = in[(size_t)t * 20 + i]; x2[i] = in[(size_t)t * 20 + 10 + i]; }
         for (int i = 0; i < 90; i++) Eb[i] = 0;
-        const int nm = five_point(x1, x2, Eb);
+        const int nm = five_point<false>(x1, x2, Eb);
         out[(size_t)t * 91] = nm;
         for (int i = 0; i < 90; i++) out[(size_t)t * 91 + 1 + i] = (i < 9 * nm || (FP_CLOCKS_ON && i >= 80)) ? Eb[i] : 0.0;
     }
