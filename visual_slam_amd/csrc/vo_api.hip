@@ -190,6 +190,7 @@ static int ctx_init(vo_ctx* c) {
     // extra lanes: one per chunk a pose wave holds, at most VO_MAX_LANES in all (a single-pair context has none)
     int nl = (int)std::min<long>(VO_MAX_LANES, ((long)c->max_pairs + c->chunk_pairs - 1) / c->chunk_pairs);
     if (const char* e = getenv("VO_LANES")) nl = std::max(1, std::min(8, atoi(e)));   // experiments
+    c->single_lane = nl == 1;
     int rc = lane_init(c, nl <= 2);
     if (rc != VO_OK) return rc;
     HIP_TRY(c, hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming));

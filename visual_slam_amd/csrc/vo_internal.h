@@ -135,6 +135,7 @@ struct vo_ctx {
     // Lanes: the context is lane 0; `lanes` are shallow clones owning a chunk workspace + streams of their own and
     // aliasing the geometry tables and pair arrays of `owner` (vo_api.hip: lane_init / lane_alias_shared).
     vo_ctx* owner = nullptr;
+    bool single_lane = false;   // the context has no extra lanes (a single-pair context): nothing runs beside its kernels
     std::vector<vo_ctx*> lanes;
     int last_lane = 0;                              // lane of the last chunk (vo_debug_read)
     // asynchronous submissions (vo_pairs_submit_device / vo_pairs_wait): at most two in flight, one per slot
