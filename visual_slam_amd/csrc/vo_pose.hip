@@ -1206,7 +1206,9 @@ int vo_launch_ransac(vo_ctx* c, int P, const double K[9], double prob, double th
         if (!host_free) HIP_TRY(c, hipMemsetAsync(active, 0, sizeof(int), st));
         hipLaunchKernelGGL(k_ransac_sample, dim3(pb), dim3(64), 0, st, pw, nmatch, P, nh, samples);
         // few hypotheses in the round (single pairs, small batches): a DPP row per hypothesis, one wavefront per SIMD at most
-        if ((long)P * nh <= VO_WIDE_SOLVE_MAX_HYP)
+        // (the asynchronous entry points overlap the pose stage with the next submission's detect kernels, where the 16-lane form's
+        // ten-fold VALU work would cost throughput: they only take it for rounds of <= 512 hypotheses)
+        if ((long)P * nh <= (host_free ? 512 : VO_WIDE_SOLVE_MAX_HYP))
             hipLaunchKernelGGL(k_ransac_solve_wide, dim3((P * nh * 16 + DK_T - 1) / DK_T), dim3(DK_T), 0, st, pw, nmatch, P, nh, kp_cap, q1, q2, nk, samples, models, nmodels);
         else
             hipLaunchKernelGGL(k_ransac_solve, dim3((P * nh + DK_T - 1) / DK_T), dim3(DK_T), 0, st, pw, nmatch, P, nh, kp_cap, q1, q2, nk, samples, models, nmodels);
