@@ -395,3 +395,27 @@ def test_full_size_batch_is_a_permutation_of_its_pairs():
         assert np.array_equal(sync[f], alone[f][idx]), f
         assert np.array_equal(first[f], alone[f][idx]), f
         assert np.array_equal(second[f], alone[f][idx[1000:]]), f
+
+
+def test_both_solver_forms_give_the_same_records(K02):
+    """A pose wave of few pairs runs the 16-lanes-per-hypothesis five-point solver, a large one the one-lane kernel (switch at
+    2048 hypotheses per RANSAC round, vo_pose.hip): the same pairs must come out bit for bit the same either way."""
+    import torch
+    from visual_slam_amd import _lib, synth
+    a, b = synth.make_batch(range(6), workers=1)
+    reps = 27                                            # 162 pairs x 16 first-round hypotheses = 2592 > 2048
+    A = np.concatenate([a] * reps); B = np.concatenate([b] * reps)
+    n, h, w = A.shape
+    K = synth.K_KITTI02
+    dA = torch.from_numpy(A).cuda(); dB = torch.from_numpy(B).cuda()
+    big = _lib.Context(max_w=w, max_h=h, chunk_pairs=32, max_pairs=n)
+    small = _lib.Context(max_w=w, max_h=h, chunk_pairs=6, max_pairs=6)
+    try:
+        one_lane = big.pairs_run_device(dA.data_ptr(), dB.data_ptr(), n, w, h, w, K)
+        wide = small.pairs_run_device(dA.data_ptr(), dB.data_ptr(), 6, w, h, w, K)
+    finally:
+        big.close(); small.close()
+    assert (wide["status"] == 0).all()
+    for f in wide.dtype.names:
+        v = one_lane[f].reshape(reps, 6, *one_lane[f].shape[1:])
+        assert all(np.array_equal(v[r], wide[f]) for r in range(reps)), f
