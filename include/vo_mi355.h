@@ -131,6 +131,12 @@ int vo_triangulate(vo_ctx* ctx, const double P1[12], const double P2[12], const 
 int vo_get_matches(vo_ctx* ctx, const uint8_t* imgA, const uint8_t* imgB, int w, int h, int stride, double ratio,
                    float* q1, float* q2, int cap, int* n);
 
+/* Replaces the whole of get_pose (libs/vo_utils.py:136-145: findEssentialMat(q1, q2, K, prob 0.999, threshold 1.0) ->
+ * recoverPose(E, q1, q2, K) -> form_transf(R, t)) in one call: q1, q2 host float32 [n][2] as get_matches returns them,
+ * T = row-major 4x4 [R t; 0 1].  n_inliers (RANSAC) and n_good (cheirality) may be NULL.  Same results as
+ * vo_find_essential_ransac + vo_recover_pose with those arguments; VO_ERR_TOO_FEW / VO_ERR_NO_MODEL as there. */
+int vo_get_pose(vo_ctx* ctx, const float* q1, const float* q2, int n, const double K[9], double T[16], int* n_inliers, int* n_good);
+
 /* The whole per-pair path for a batch of B independent frame pairs whose images are
  * already resident in device memory: imgsA/imgsB are dev pointers to [B][h][stride]
  * uint8 (previous / current frames).  out: HOST array [B].  Detect+match run in chunks of

@@ -419,3 +419,18 @@ def test_both_solver_forms_give_the_same_records(K02):
     for f in wide.dtype.names:
         v = one_lane[f].reshape(reps, 6, *one_lane[f].shape[1:])
         assert all(np.array_equal(v[r], wide[f]) for r in range(reps)), f
+
+
+def test_get_pose_one_call_equals_the_two_calls(ctx, K02):
+    for seed, n, noise, outl in [(0, 200, 0.0, 0), (3, 400, 0.3, 120), (11, 300, 0.2, 200)]:
+        x1, x2, *_ = two_view(seed, n, K02, noise=noise, outliers=outl)
+        E, mask, ninl = ctx.find_essential_ransac(x1, x2, K02)
+        R, t, ng = ctx.recover_pose(E, x1, x2, K02)
+        T, ni2, ng2 = ctx.get_pose(x1, x2, K02)
+        assert (ni2, ng2) == (ninl, ng)
+        assert np.array_equal(T[:3, :3], R) and np.array_equal(T[:3, 3], t.reshape(3)) and np.array_equal(T[3], [0, 0, 0, 1])
+    from visual_slam_amd._lib import VoError, VO_ERR_TOO_FEW
+    x1, x2, *_ = two_view(0, 4, K02)
+    with pytest.raises(VoError) as e:
+        ctx.get_pose(x1, x2, K02)
+    assert e.value.code == VO_ERR_TOO_FEW

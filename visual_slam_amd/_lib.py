@@ -36,7 +36,7 @@ PAIR_DTYPE = np.dtype([("T", "<f8", (4, 4)), ("n_kp1", "<i4"), ("n_kp2", "<i4"),
 EXPORTS = [
     "vo_default_orb_params", "vo_ctx_create", "vo_ctx_destroy", "vo_last_error", "vo_orb_detect_compute", "vo_match_knn2_ratio",
     "vo_match_knn2", "vo_find_essential_ransac", "vo_recover_pose", "vo_triangulate", "vo_pairs_run_device", "vo_pairs_run", "vo_sequence_run_device", "vo_sequence_run", "vo_ba_plan_create", "vo_ba_plan_destroy", "vo_ba_pass_device", "vo_ba_pass",
-    "vo_match_knn2_ratio_noalloc", "vo_get_matches", "vo_pairs_triangulate", "vo_pairs_submit_device", "vo_sequence_submit_device", "vo_pairs_wait", "vo_debug_read", "vo_debug_minimal_solver", "vo_set_debug_stop", "vo_set_kernel_timing", "vo_get_kernel_timing",
+    "vo_match_knn2_ratio_noalloc", "vo_get_matches", "vo_get_pose", "vo_pairs_triangulate", "vo_pairs_submit_device", "vo_sequence_submit_device", "vo_pairs_wait", "vo_debug_read", "vo_debug_minimal_solver", "vo_set_debug_stop", "vo_set_kernel_timing", "vo_get_kernel_timing",
 ]
 
 _lib = None
@@ -88,6 +88,7 @@ def load():
     lib.vo_debug_read.argtypes = [vp, i, i, i, vp, C.c_long]
     lib.vo_debug_read.restype = C.c_long
     lib.vo_debug_minimal_solver.argtypes = [vp, i, vp, i, vp]
+    lib.vo_get_pose.argtypes = [vp, vp, vp, i, vp, vp, vp, vp]
     lib.vo_set_debug_stop.argtypes = [vp, i]
     lib.vo_set_kernel_timing.argtypes = [vp, i]
     lib.vo_get_kernel_timing.argtypes = [vp, vp, vp]
@@ -185,6 +186,15 @@ class Context:
         E = np.zeros((3, 3)); mask = np.zeros(max(n, 1), np.uint8); ninl = C.c_int(0)
         self._check(self.lib.vo_find_essential_ransac(self.h, _ptr(q1), _ptr(q2), n, _ptr(K), prob, thr, max_iters, _ptr(E), _ptr(mask), C.byref(ninl)))
         return E, mask[:n].copy(), ninl.value
+
+    def get_pose(self, q1, q2, K):
+        """findEssentialMat + recoverPose + form_transf in one call (libs/vo_utils.py:136-145) -> (T 4x4, n_inliers, n_good)"""
+        q1 = np.ascontiguousarray(q1, np.float32).reshape(-1, 2)
+        q2 = np.ascontiguousarray(q2, np.float32).reshape(-1, 2)
+        K = np.ascontiguousarray(K, np.float64)
+        T = np.zeros((4, 4)); ni = C.c_int(0); ng = C.c_int(0)
+        self._check(self.lib.vo_get_pose(self.h, _ptr(q1), _ptr(q2), len(q1), _ptr(K), _ptr(T), C.byref(ni), C.byref(ng)))
+        return T, ni.value, ng.value
 
     def recover_pose(self, E, q1, q2, K, dist_thresh=50.0):
         q1 = np.ascontiguousarray(q1, np.float32).reshape(-1, 2)

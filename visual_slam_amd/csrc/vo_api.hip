@@ -491,6 +491,34 @@ int vo_recover_pose(vo_ctx* c, const double E[9], const float* q1, const float* 
     return VO_OK;
 }
 
+// get_pose (libs/vo_utils.py:136-145) as one call: findEssentialMat(prob 0.999, threshold 1.0, 1000 iterations), recoverPose
+// (distance threshold 50) and form_transf, the points uploaded once and one read-back at the end.
+int vo_get_pose(vo_ctx* c, const float* q1, const float* q2, int n, const double K[9], double T[16], int* n_inliers, int* n_good) {
+    if (!c) return VO_ERR_INVALID;
+    if (!q1 || !q2 || !K || !T || n < 0) return vo_fail(c, VO_ERR_INVALID, "vo_get_pose: bad arguments");
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    int rc = upload_points(c, q1, q2, n, st);
+    if (rc != VO_OK) return rc;
+    c->last_pairs = 1;
+    rc = vo_launch_ransac(c, 1, K, 0.999, 1.0, 1000, st);
+    if (rc == VO_OK) rc = vo_launch_recover(c, 1, K, 50.0, st);     // a pair without a model is skipped by the kernels
+    if (rc != VO_OK) return rc;
+    PoseWork w;
+    HIP_TRY(c, hipMemcpyAsync(&w, c->d_pose.p, sizeof(w), hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipStreamSynchronize(st));
+    if (n_inliers) *n_inliers = w.status == VO_OK ? w.max_good : 0;
+    if (n_good) *n_good = w.status == VO_OK ? w.n_good : 0;
+    if (w.status == VO_ERR_TOO_FEW) return vo_fail(c, VO_ERR_TOO_FEW, "findEssentialMat needs at least 5 points");
+    if (w.status != VO_OK) return vo_fail(c, w.status, "findEssentialMat: RANSAC found no model");
+    for (int i = 0; i < 3; i++) {
+        for (int j = 0; j < 3; j++) T[4 * i + j] = w.R[3 * i + j];
+        T[4 * i + 3] = w.t[i];
+    }
+    T[12] = T[13] = T[14] = 0; T[15] = 1;
+    return VO_OK;
+}
+
 int vo_triangulate(vo_ctx* c, const double P1[12], const double P2[12], const float* x1, const float* x2, int n, float* X4) {
     if (!c) return VO_ERR_INVALID;
     if (!P1 || !P2 || !x1 || !x2 || !X4 || n < 0) return vo_fail(c, VO_ERR_INVALID, "vo_triangulate: bad arguments");

@@ -119,9 +119,8 @@ class VisualOdometry():
         q1 = np.asarray(q1, np.float32).reshape(-1, 2)
         q2 = np.asarray(q2, np.float32).reshape(-1, 2)
         ctx = self._ctx if self._ctx is not None else self._context(376, 1241)
-        E, mask, _ = ctx.find_essential_ransac(q1, q2, self.K, 0.999, 1.0, 1000)
-        R, tvec, _ = ctx.recover_pose(E, q1, q2, self.K, 50.0)
-        return self.form_transf(R, tvec.squeeze())
+        T, _, _ = ctx.get_pose(q1, q2, self.K)     # one library call: RANSAC + recoverPose + form_transf
+        return T
 
     def triangulate(self, pts1, pts2, P1, P2):
         """Triangulate 3d points from corresponding 2d matching points (libs/vo_utils.py:148-164).
