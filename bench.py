@@ -290,6 +290,8 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo to rehearse several ranks on one GPU)")
     ap.add_argument("--config4", action="store_true",
                     help="diagnostic: run configs[3] instead (3840x2160 frames, 20000 ORB features; use e.g. --pairs 64 --chunk 16 --streams 2 --steps 3)")
+    ap.add_argument("--dump-records", default=None, help="rank 0 writes the last step's gathered per-pair records (numpy .npy, PAIR_DTYPE) to this path")
+    ap.add_argument("--config4-pairs", type=int, default=16, help="pairs of the small configs[3] leg that the default N = 1 run carries (0 = leave it out)")
     ap.add_argument("--kitti-pairs", type=int, default=1024, help="pairs in the configs[0] leg (the bundled KITTI frames, tiled)")
     args = ap.parse_args()
     W_IMG, H_IMG, NFEAT = (3840, 2160, 20000) if args.config4 else (1241, 376, 3000)
@@ -322,6 +324,12 @@ def main():
     if nd < B:  # diagnostic: tile the distinct pairs up to the shard size (same work per pair, shorter set-up)
         idx = np.arange(B) % nd
         imgsA, imgsB = imgsA[idx], imgsB[idx]
+    # side legs at N = 1 (none of them part of `value`): h2d / png_decode / latency / kitti, and since round 3 also
+    # sequence mode, configs[3] (a small 4K leg) and configs[4] (the BA pass, which runs at every N)
+    side_legs = rank == 0 and world == 1 and not args.no_extras and not args.config4
+    c4A = c4B = None
+    if side_legs and args.config4_pairs > 0:
+        c4A, c4B = synth.make_batch(range(args.config4_pairs), 3840, 2160, workers=workers)
 
     import torch
     import torch.distributed as dist
@@ -446,7 +454,7 @@ def main():
                                    "equiv_xor_popcount_Tlaneops": round(float(nk.sum()) * 16.0 / (kernels["k_match"]["ms_total"] * 1e-3) / 1e12, 2),
                                    "valu_xor_popcount_ceiling_Tlaneops": 36.1}
 
-    extras = rank == 0 and world == 1 and not args.no_extras and not args.config4      # the side legs are measured at N = 1 only
+    extras = side_legs                                                                 # the side legs are measured at N = 1 only
     h2d = latency = kitti = png = None
     if extras:
         # ---- H2D copy, reported separately (never part of `value`): pinned host memory -> HBM, and the library's host-image
@@ -601,7 +609,7 @@ def main():
                 pass
 
     seq = None
-    if rank == 0 and args.sequence:
+    if rank == 0 and (args.sequence or extras):
         # same kernels on S sequences, one per context: A_k, B_k, A_k, B_k, ... of ONE pair k each, so that every consecutive
         # pair is a pair of related views (forward or reverse motion) and none dies at the ratio test; each frame is
         # extracted once per chunk
@@ -640,8 +648,49 @@ def main():
                "pairs_total": int(len(r2)), "note": "consecutive-pair mode (SURVEY 8(f) N3): one sequence per context, each frame extracted once per chunk"}
         del seqs
 
+    config4 = None
+    if extras and c4A is not None:
+        # ---- configs[3]: 3840x2160 frames, 20000 ORB features, K scaled: a small leg (16 pairs by default, chunks of 8) so that the
+        # driver's record carries the O(N^2) matcher case; `--config4 --pairs 64 --chunk 16` is the full-size diagnostic
+        W4, H4, NF4 = 3840, 2160, 20000
+        A4, P4 = algo_bytes_per_frame(W4, H4, NF4)
+        K4 = synth.config_K(W4, H4)
+        n4 = len(c4A)
+        d4A = torch.from_numpy(c4A).cuda(); d4B = torch.from_numpy(c4B).cuda()
+        c4 = _lib.Context(max_w=W4, max_h=H4, chunk_pairs=min(8, n4), max_pairs=n4, device=local_rank, nfeatures=NF4)
+        c4.pairs_run_device(d4A.data_ptr(), d4B.data_ptr(), n4, W4, H4, W4, K4)
+        torch.cuda.synchronize()
+        steps4 = 3
+        t1 = time.perf_counter()
+        for k in range(steps4):
+            c4.pairs_submit_device(d4A.data_ptr(), d4B.data_ptr(), n4, W4, H4, W4, K4)
+            if k >= 1:
+                r4 = c4.pairs_wait()
+        r4 = c4.pairs_wait()
+        torch.cuda.synchronize()
+        dt4 = time.perf_counter() - t1
+        c4.set_kernel_timing(True)
+        r4t = c4.pairs_run_device(d4A.data_ptr(), d4B.data_ptr(), n4, W4, H4, W4, K4)
+        kt4 = c4.kernel_timing()
+        c4.set_kernel_timing(False)
+        c4.close()
+        fpl4 = 2 * min(8, n4)
+        k4 = {name: {"ms_total": round(ms, 4), "launches": n, "avg_ms": round(ms / n, 5)} for name, (ms, n) in kt4.items() if n}
+        config4 = {"workload": "configs[3]: %d synthetic 3840x2160 pairs (seeds 0..%d), 20000 ORB features, K scaled x3.094, chunks of %d pairs" % (n4, n4 - 1, min(8, n4)),
+                   "frame_pairs_per_sec": round(n4 * steps4 / dt4, 2), "steps": steps4, "pairs_ok": int((r4["status"] == 0).sum()), "pairs_total": int(len(r4)),
+                   "mean_keypoints": round(float(r4["n_kp1"].mean()), 1), "mean_matches": round(float(r4["n_match"].mean()), 1), "mean_inliers": round(float(r4["n_inlier"].mean()), 1),
+                   "per_kernel_GBps": {k: round(A4[k] * fpl4 / (7 if k == "k_pyramid" else 1) / (k4[k]["avg_ms"] * 1e-3) / 1e9, 1) for k in A4 if k in k4},
+                   "kernels": k4}
+        if "k_match" in k4:
+            ops4 = float((r4t["n_kp1"].astype(np.float64) * r4t["n_kp2"].astype(np.float64)).sum()) * 512.0
+            a4 = ops4 / (k4["k_match"]["ms_total"] * 1e-3) / 1e12
+            config4["matcher"] = {"bound": "mfma", "achieved": round(a4, 1), "peak": round(MFMA_I8_PEAK_TOPS, 1), "unit": "TOP/s (i8)", "frac": round(a4 / MFMA_I8_PEAK_TOPS, 4)}
+        del d4A, d4B
+
     ba_out = None
-    if args.ba:
+    if args.ba or (not args.no_extras and not args.config4):
+        # ---- configs[4]: the BA residual / Jacobian pass; points (and their observations) sharded over the ranks, the pose
+        # blocks all-reduced (RCCL at N > 1).  Runs at every N; never part of `value`.
         from visual_slam_amd import ba as BA
         pr = BA.synth_problem(1000, 200000, 5, seed=0)
         sh = BA.shard_observations(pr, rank, world)
@@ -667,15 +716,53 @@ def main():
             ba_step()
         barrier()
         ba_dt = parallel.max_over_ranks((time.perf_counter() - t1) / 20)
+        # algorithmic HBM bytes of one pass over this rank's M observations: read uv 16 + the two indices 8 per
+        # observation and every point once (24 B); write r 16 + norm 8 + Hpl 144 per observation, Hll 72 + bl 24 per point,
+        # Hpp + bp 336 per pose (the replicated pose table is 48 KB: left out)
+        npts = int(len(np.unique(sh["obs_point"])))
+        ba_bytes = M * (16 + 8 + 16 + 8 + 144) + npts * (24 + 72 + 24) + 1000 * 336
         ba_out = {"workload": "configs[4]: 1000 poses x 200000 points x 5 observations, fp64, residuals + Hpp/bp/Hll/bl/Hpl", "ms_per_pass": round(ba_dt * 1e3, 4),
                   "observations_per_sec": round(1e6 / ba_dt, 1), "rms_residual_px": round(float(torch.sqrt((o_n ** 2).mean())), 4),
                   "collective": "all_reduce of [1000,42] f64 pose blocks" if world > 1 else "none (1 rank)"}
+        if rank == 0:
+            # the kernels one at a time, HIP events on the stream they are launched on (a torch side stream handed to the library)
+            side = torch.cuda.Stream(device=dev)
+            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+            kb = {}
+            with torch.cuda.stream(side):
+                for _ in range(2):
+                    plan.run_device(t_p.data_ptr(), t_x.data_ptr(), t_uv.data_ptr(), pr["K"], o_r.data_ptr(), o_n.data_ptr(), o_Hpp.data_ptr(),
+                                    o_bp.data_ptr(), o_Hll.data_ptr(), o_bl.data_ptr(), o_Hpl.data_ptr(), stream=side.cuda_stream)
+                side.synchronize()
+                e0.record(side)
+                for _ in range(10):
+                    plan.run_device(t_p.data_ptr(), t_x.data_ptr(), t_uv.data_ptr(), pr["K"], o_r.data_ptr(), o_n.data_ptr(), o_Hpp.data_ptr(),
+                                    o_bp.data_ptr(), o_Hll.data_ptr(), o_bl.data_ptr(), o_Hpl.data_ptr(), stream=side.cuda_stream)
+                e1.record(side)
+                side.synchronize()
+                kb["whole_pass"] = e0.elapsed_time(e1) / 10
+                for name, outs in (("obs(r,norm,Hpl)", (o_r.data_ptr(), o_n.data_ptr(), 0, 0, 0, 0, o_Hpl.data_ptr())),
+                                   ("pose(Hpp,bp)", (0, 0, o_Hpp.data_ptr(), o_bp.data_ptr(), 0, 0, 0)),
+                                   ("point(Hll,bl)", (0, 0, 0, 0, o_Hll.data_ptr(), o_bl.data_ptr(), 0))):
+                    e0.record(side)
+                    for _ in range(10):
+                        plan.run_device(t_p.data_ptr(), t_x.data_ptr(), t_uv.data_ptr(), pr["K"], *outs, stream=side.cuda_stream)
+                    e1.record(side)
+                    side.synchronize()
+                    kb[name] = e0.elapsed_time(e1) / 10
+            a_ba = ba_bytes / (kb["whole_pass"] * 1e-3) / 1e9
+            ba_out["roofline"] = {"bound": "hbm", "achieved": round(a_ba, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(a_ba / HBM_PEAK_GBS, 4),
+                                  "bytes_per_pass": int(ba_bytes), "device_ms_per_pass": round(kb["whole_pass"], 5),
+                                  "device_ms_by_outputs": {k: round(v, 5) for k, v in kb.items() if k != "whole_pass"},
+                                  "note": "HIP events on the launch stream, 10 passes back to back; ms_per_pass above is host wall clock per synchronous call (+ the all-reduce at N > 1)"}
         plan.close()
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu:      # on rank 0 at N = 1 only
         cpu = cpu_baseline(imgsA, imgsB, K, NFEAT)
 
+    if rank == 0 and args.dump_records:
+        np.save(args.dump_records, res)
     if rank == 0:
         value = G * args.steps / dt
         out = {
@@ -689,7 +776,7 @@ def main():
                        "contexts_join_every_step": bool(args.join_steps), "calls": "synchronous" if (args.sync_calls or args.pose_batch > 0) else "submit/wait, 2 in flight", "parallelism": "pairs sharded contiguously over ranks, no data-path collective; all_gather of 152-byte records per step",
                        "pairs_ok": ok, "pairs_total": int(len(res)), "timed_region_s": round(dt, 3), "input_generation_s": round(t_gen, 1)},
             "roofline": roofline, "cpu_baseline": cpu, "h2d": h2d, "png_decode": png, "latency": latency, "kitti": kitti,
-            "sequence_mode": seq, "ba_pass": ba_out, "kernels": kernels,
+            "sequence_mode": seq, "config4": config4, "ba_pass": ba_out, "kernels": kernels,
         }
         print(json.dumps(out))
     if world > 1:

@@ -96,7 +96,7 @@ int vo_match_knn2(vo_ctx* ctx, const uint8_t* q, int nq, const uint8_t* t, int n
 /* The matcher for callers that cannot allocate (code under HIP graph capture, tight serving loops,
  * harnesses that forbid hipMalloc).  It has NO counterpart in the reference: it is vo_match_knn2_ratio
  * with device pointers in and out, and with the kernels' workspace (staged descriptors, per-segment
- * best/second keys, compacted rows, counters: 458,880 bytes) in a file-scope device array instead of
+ * best/second keys, compacted rows, counters: 459,008 bytes) in a file-scope device array instead of
  * the context's buffers; its address on the context's GPU is resolved once, in vo_ctx_create.
  * q_dev [nq][32], t_dev [nt][32]: device memory.  matches_dev: device int32 [cap][4] = queryIdx,
  * trainIdx, d1, d2 of the kept matches in ascending queryIdx; *n_dev (device int32) receives their

@@ -141,10 +141,25 @@ def test_submit_wait_equals_synchronous_calls(kitti02, K02):
     with pytest.raises(_lib.VoError):
         ctx.pairs_run_device(dA.data_ptr(), dB.data_ptr(), 4, w, h, w, K)   # synchronous calls are refused while one is in flight
     with pytest.raises(_lib.VoError):
+        # refused BEFORE the geometry tables are rebuilt for another frame size (the lanes in flight read them): ADVICE r2
+        ctx.pairs_run_device(dA.data_ptr(), dB.data_ptr(), 4, w - 64, h - 32, w, K)
+    with pytest.raises(_lib.VoError):
+        ctx.sequence_run_device(dA.data_ptr(), 4, w - 64, h - 32, w, K)
+    with pytest.raises(_lib.VoError):
+        ctx.pairs_run(A[:2, :h - 32, :w - 64], B[:2, :h - 32, :w - 64], K)
+    with pytest.raises(_lib.VoError):
+        ctx.sequence_run(A[:3, :h - 32, :w - 64], K)
+    with pytest.raises(_lib.VoError):
         ctx.pairs_triangulate(P, P)                                          # and so is everything else that shares its buffers
     with pytest.raises(_lib.VoError):
         ctx.pairs_submit_device(dA.data_ptr(), dB.data_ptr(), 9, w, h, w, K)   # more than max_pairs
-    assert _records_equal(ctx.pairs_wait(), want[0][:4])
+    assert _records_equal(ctx.pairs_wait(), want[0][:4])                      # the refused calls left the submission intact
+    # the per-pair status vo_pairs_triangulate relies on is only written by the batched pose waves: after a single-pair
+    # entry point it is stale, and the call is refused instead of emitting points by a leftover status
+    ctx.pairs_triangulate(P[:4], P[:4])
+    ctx.get_matches(A[0], B[0])
+    with pytest.raises(_lib.VoError):
+        ctx.pairs_triangulate(P[:1], P[:1])
     ctx.close()
 
 

@@ -276,8 +276,13 @@ class Context:
 
     def pairs_wait(self):
         """Records of the oldest submission in flight."""
+        if not self._inflight:
+            self._check(self.lib.vo_pairs_wait(self.h))       # raises: nothing in flight
+        # vo_pairs_wait retires the oldest submission whether or not it succeeds: mirror that, so the queue here and the
+        # library's n_waited never get out of step
+        out = self._inflight.pop(0)
         self._check(self.lib.vo_pairs_wait(self.h))
-        return self._inflight.pop(0)
+        return out
 
     def sequence_run(self, imgs, K, ratio=0.45):
         """imgs: uint8 [F,h,w] consecutive frames (host).  Returns PAIR_DTYPE [F-1]: pair i = (frame i, frame i+1)."""

@@ -386,7 +386,7 @@ static int match_host(vo_ctx* c, const uint8_t* q, int nq, const uint8_t* t, int
     HIP_TRY(c, hipMemsetAsync(c->d_frame_status.p, 0, 8, st));
     if (nq) HIP_TRY(c, hipMemcpyAsync(c->d_desc.p, q, (size_t)nq * 32, hipMemcpyHostToDevice, st));
     HIP_TRY(c, hipMemcpyAsync((uint8_t*)c->d_desc.p + kc * 32, t, (size_t)nt * 32, hipMemcpyHostToDevice, st));
-    c->last_pairs = 1; c->last_lane = 0;
+    c->last_pairs = 1; c->last_lane = 0; c->results_valid = false;
     int rc = vo_launch_match_impl(c, 1, 1, ratio, 0, want_raw ? (int4*)c->d_raw.p : nullptr, st);
     if (rc != VO_OK) return rc;
     HIP_TRY(c, hipStreamSynchronize(st));
@@ -435,6 +435,7 @@ static int upload_points(vo_ctx* c, const float* q1, const float* q2, int n, hip
     REFUSE_IN_FLIGHT(c, "pose entry point");
     int hn = n, zero = 0;
     c->slot = 0;
+    c->results_valid = false;    // pair 0 of the pair arrays is overwritten; d_result still describes the last pose wave
     HIP_TRY(c, hipMemcpyAsync(c->nmatch(), &hn, 4, hipMemcpyHostToDevice, st));
     HIP_TRY(c, hipMemcpyAsync(c->pair_status(), &zero, 4, hipMemcpyHostToDevice, st));
     if (n) {
@@ -550,6 +551,7 @@ int vo_triangulate(vo_ctx* c, const double P1[12], const double P2[12], const fl
 // pose stage (findEssentialMat + recoverPose) over the Pb pairs matched so far, results to host
 static int pose_stage(vo_ctx* c, int Pb, const double K[9], vo_pair_result* out, hipStream_t st, const std::vector<hipEvent_t>& after = {}) {
     c->last_pairs = Pb;
+    c->results_valid = false;
     for (hipEvent_t e : after) HIP_TRY(c, hipStreamWaitEvent(st, e, 0));
     kt_begin(c, st, VO_K_RANSAC);
     int rc = vo_launch_ransac(c, Pb, K, 0.999, 1.0, 1000, st);
@@ -564,6 +566,7 @@ static int pose_stage(vo_ctx* c, int Pb, const double K[9], vo_pair_result* out,
     HIP_TRY(c, hipMemcpyAsync(out, c->d_result.p, (size_t)Pb * sizeof(vo_pair_result), hipMemcpyDeviceToHost, st));
     HIP_TRY(c, hipStreamSynchronize(st));
     if (c->timing) kt_collect(c);
+    c->results_valid = true;    // d_result now describes the pair arrays of c->slot
     return VO_OK;
 }
 
@@ -606,6 +609,7 @@ static int run_batches(vo_ctx* c, int B, int cp, const double K[9], vo_pair_resu
     auto drain = [&](int r) {
         for (hipStream_t s : lst) (void)hipStreamSynchronize(s);
         (void)hipStreamSynchronize(pst);
+        c->results_valid = false;
         return r;
     };
     struct Pending { int b0 = -1, Pb = 0, slot = 0; std::vector<hipEvent_t> ev; } pend;
@@ -669,6 +673,7 @@ int vo_pairs_run_device(vo_ctx* c, const uint8_t* imgsA, const uint8_t* imgsB, i
     if (!c) return VO_ERR_INVALID;
     if (!imgsA || !imgsB || !K || !out || B < 0 || stride < w) return vo_fail(c, VO_ERR_INVALID, "vo_pairs_run_device: bad arguments");
     if (B == 0) return VO_OK;
+    REFUSE_IN_FLIGHT(c, "vo_pairs_run_device");   // before the geometry tables are touched: the lanes in flight read them
     HIP_TRY(c, hipSetDevice(c->device));
     int rc = vo_build_geometry(c, w, h);
     if (rc != VO_OK) return rc;
@@ -705,6 +710,14 @@ static int submit_impl(vo_ctx* c, const char* name, int B, int cp, int w, int h,
     for (int i = 0; i < nl; i++) lst[i] = lane(i)->stream;
     rc = order_after(c, user, lst);
     if (rc != VO_OK) return rc;
+    hipStream_t pst = c->pose_stream;
+    // A failure after the first enqueue leaves kernels writing this slot's pair arrays while the context looks idle
+    // (n_submitted is not advanced): wait for them before returning, as run_batches does on its error paths.
+    auto drain = [&](int r) {
+        for (hipStream_t s : lst) (void)hipStreamSynchronize(s);
+        (void)hipStreamSynchronize(pst);
+        return r;
+    };
     unsigned used = 0;
     int nchunk = 0;
     for (int p0 = 0; p0 < B; p0 += cp, nchunk++) {
@@ -712,24 +725,25 @@ static int submit_impl(vo_ctx* c, const char* name, int B, int cp, int w, int h,
         vo_ctx* L = lane(li);
         L->slot = slot;
         rc = chunk(L, lst[li], p0, std::min(cp, B - p0));
-        if (rc != VO_OK) return L != c ? vo_fail(c, rc, L->err) : rc;
+        if (rc != VO_OK) return drain(L != c ? vo_fail(c, rc, L->err) : rc);
         c->last_lane = li;
         used |= 1u << li;
     }
-    hipStream_t pst = c->pose_stream;
     for (int li = 0; li < nl; li++)
         if (used >> li & 1) {
-            HIP_TRY(c, hipEventRecord(lane(li)->ev_lane[slot], lst[li]));
-            HIP_TRY(c, hipStreamWaitEvent(pst, lane(li)->ev_lane[slot], 0));
+            if (hipEventRecord(lane(li)->ev_lane[slot], lst[li]) != hipSuccess || hipStreamWaitEvent(pst, lane(li)->ev_lane[slot], 0) != hipSuccess)
+                return drain(vo_fail(c, VO_ERR_HIP, std::string(name) + ": could not order the pose stream after the lanes"));
         }
     c->slot = slot;
     rc = vo_launch_ransac(c, B, K, 0.999, 1.0, 1000, pst, true);
     if (rc == VO_OK) rc = vo_launch_recover(c, B, K, 50.0, pst);
-    if (rc != VO_OK) return rc;
+    if (rc != VO_OK) return drain(rc);
     hipLaunchKernelGGL(k_results, dim3((B + 63) / 64), dim3(64), 0, pst, (const PoseWork*)c->d_pose.p, (const int*)c->nmatch(),
                        (const int2*)c->pair_nkp(), B, (vo_pair_result*)c->d_result.p);
-    HIP_TRY(c, hipMemcpyAsync(c->h_result + (size_t)slot * c->max_pairs, c->d_result.p, (size_t)B * sizeof(vo_pair_result), hipMemcpyDeviceToHost, pst));
-    HIP_TRY(c, hipEventRecord(c->ev_done[slot], pst));
+    if (hipMemcpyAsync(c->h_result + (size_t)slot * c->max_pairs, c->d_result.p, (size_t)B * sizeof(vo_pair_result), hipMemcpyDeviceToHost, pst) != hipSuccess ||
+        hipEventRecord(c->ev_done[slot], pst) != hipSuccess)
+        return drain(vo_fail(c, VO_ERR_HIP, std::string(name) + ": could not enqueue the read-back"));
+    c->results_valid = false;   // d_result is being rewritten; vo_pairs_wait marks it valid again
     c->sub[slot].live = true; c->sub[slot].B = B; c->sub[slot].out = out;
     c->n_submitted++;
     return VO_OK;
@@ -772,11 +786,19 @@ int vo_pairs_wait(vo_ctx* c) {
     if (c->n_submitted == c->n_waited) return vo_fail(c, VO_ERR_INVALID, "vo_pairs_wait: nothing in flight");
     HIP_TRY(c, hipSetDevice(c->device));
     const int slot = (int)(c->n_waited & 1);
-    HIP_TRY(c, hipEventSynchronize(c->ev_done[slot]));
-    memcpy(c->sub[slot].out, c->h_result + (size_t)slot * c->max_pairs, (size_t)c->sub[slot].B * sizeof(vo_pair_result));
+    const hipError_t e = hipEventSynchronize(c->ev_done[slot]);
+    // the submission is retired whatever the outcome: a context whose wait failed must not stay "in flight" for good
     c->sub[slot].live = false;
     c->n_waited++;
+    if (e != hipSuccess) {
+        c->results_valid = false; c->last_pairs = 0;
+        (void)hipDeviceSynchronize();     // nothing of the failed submission may still be writing the pair arrays
+        return vo_fail(c, VO_ERR_HIP, std::string("vo_pairs_wait: ") + hipGetErrorString(e) + " (the submission is dropped, its records are not written)");
+    }
+    memcpy(c->sub[slot].out, c->h_result + (size_t)slot * c->max_pairs, (size_t)c->sub[slot].B * sizeof(vo_pair_result));
     c->slot = slot; c->last_pairs = c->sub[slot].B;     // vo_debug_read / vo_pairs_triangulate see this submission's pair arrays
+    // d_result holds the records of the submission ENQUEUED last; it describes this slot only when none is left behind it
+    c->results_valid = c->n_submitted == c->n_waited;
     return VO_OK;
 }
 
@@ -788,6 +810,7 @@ int vo_sequence_run_device(vo_ctx* c, const uint8_t* imgs, int F, int w, int h, 
     if (!c) return VO_ERR_INVALID;
     if (!imgs || !K || !out || F < 0 || stride < w) return vo_fail(c, VO_ERR_INVALID, "vo_sequence_run_device: bad arguments");
     if (F < 2) return VO_OK;
+    REFUSE_IN_FLIGHT(c, "vo_sequence_run_device");   // before the geometry tables are touched: the lanes in flight read them
     HIP_TRY(c, hipSetDevice(c->device));
     int rc = vo_build_geometry(c, w, h);
     if (rc != VO_OK) return rc;
@@ -821,7 +844,7 @@ int vo_get_matches(vo_ctx* c, const uint8_t* imgA, const uint8_t* imgB, int w, i
     HIP_TRY(c, copy_frames_h2d(dA, imgA, w, stride, (size_t)h));
     HIP_TRY(c, copy_frames_h2d(dA + fs, imgB, w, stride, (size_t)h));
     hipStream_t st = c->stream;
-    c->slot = 0; c->last_lane = 0; c->last_pairs = 1;
+    c->slot = 0; c->last_lane = 0; c->last_pairs = 1; c->results_valid = false;
     FrameSrc src{dA, dA + fs, 1, w, fs};
     c->last_src = src; c->last_frames = 2;
     rc = vo_launch_detect(c, src, 2, st);
@@ -848,8 +871,11 @@ int vo_get_matches(vo_ctx* c, const uint8_t* imgA, const uint8_t* imgB, int w, i
 int vo_pairs_triangulate(vo_ctx* c, int P, const double* P1, const double* P2, float* X, float* q1, float* q2, long cap, int64_t* offsets) {
     if (!c) return VO_ERR_INVALID;
     if (!P1 || !P2 || !offsets || P < 0 || cap < 0) return vo_fail(c, VO_ERR_INVALID, "vo_pairs_triangulate: bad arguments");
-    if (P > c->last_pairs) return vo_fail(c, VO_ERR_INVALID, "vo_pairs_triangulate: more pairs than the last pose wave held");
     REFUSE_IN_FLIGHT(c, "vo_pairs_triangulate");
+    // the per-pair status comes from d_result, which only the batched pose waves write: after a single-pair entry point
+    // (vo_get_matches, vo_get_pose, the matcher, findEssentialMat ...) it would be a stale record of an earlier wave
+    if (!c->results_valid) return vo_fail(c, VO_ERR_INVALID, "vo_pairs_triangulate: the last call on this context was not a batched pose wave (vo_pairs_run*, vo_sequence_run*, vo_pairs_wait)");
+    if (P > c->last_pairs) return vo_fail(c, VO_ERR_INVALID, "vo_pairs_triangulate: more pairs than the last pose wave held");
     offsets[0] = 0;
     if (P == 0) return VO_OK;
     HIP_TRY(c, hipSetDevice(c->device));
@@ -897,6 +923,7 @@ int vo_sequence_run(vo_ctx* c, const uint8_t* imgs, int F, int w, int h, int str
     if (!c) return VO_ERR_INVALID;
     if (!imgs || !K || !out || F < 0 || stride < w) return vo_fail(c, VO_ERR_INVALID, "vo_sequence_run: bad arguments");
     if (F < 2) return VO_OK;
+    REFUSE_IN_FLIGHT(c, "vo_sequence_run");   // before the geometry tables are touched: the lanes in flight read them
     HIP_TRY(c, hipSetDevice(c->device));
     int rc = vo_build_geometry(c, w, h);
     if (rc != VO_OK) return rc;
@@ -922,6 +949,7 @@ int vo_pairs_run(vo_ctx* c, const uint8_t* imgsA, const uint8_t* imgsB, int B, i
     if (!c) return VO_ERR_INVALID;
     if (!imgsA || !imgsB || !K || !out || B < 0 || stride < w) return vo_fail(c, VO_ERR_INVALID, "vo_pairs_run: bad arguments");
     if (B == 0) return VO_OK;
+    REFUSE_IN_FLIGHT(c, "vo_pairs_run");   // before the geometry tables are touched: the lanes in flight read them
     HIP_TRY(c, hipSetDevice(c->device));
     int rc = vo_build_geometry(c, w, h);
     if (rc != VO_OK) return rc;

@@ -152,6 +152,7 @@ struct vo_ctx {
     // last chunk bookkeeping for vo_debug_read
     FrameSrc last_src{};
     int last_frames = 0, last_pairs = 0;
+    bool results_valid = false;   // d_result (per-pair status) describes the pair arrays of the current slot: set by the pose waves, cleared by the single-pair entry points
 
     // per-kernel timing with HIP events on the launch stream (diagnostic mode)
     bool timing = false;

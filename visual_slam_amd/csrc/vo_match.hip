@@ -278,7 +278,8 @@ int vo_launch_match_impl(vo_ctx* c, int P, int nA, double ratio, int pair0, int4
 #define NA_OFF_MQ (NA_OFF_SEG + (long)NA_NSEG * NA_CAP * 8)   // int4 [NA_CAP]
 #define NA_OFF_SMALL (NA_OFF_MQ + (long)NA_CAP * 16)          // int nkp[2], frame_status[2], nmatch, pair_status, pair_nkp[2]
 #define NA_BYTES (NA_OFF_SMALL + 256)
-static __device__ __align__(256) unsigned char scratch[NA_BYTES];   // 458,880 B per GPU, held until the process ends
+static_assert(NA_BYTES == 459008, "the documented size of the no-allocation scratch (include/vo_mi355.h, DESIGN.md, INTEGRATION.md)");
+static __device__ __align__(256) unsigned char scratch[NA_BYTES];   // 459,008 B per GPU, held until the process ends
 static void* g_scratch_ptr[64];                                     // per device: the address of ITS copy of `scratch`
 
 int vo_noalloc_init(vo_ctx* c) {
