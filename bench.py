@@ -741,20 +741,10 @@ def main():
                 e1.record(side)
                 side.synchronize()
                 kb["whole_pass"] = e0.elapsed_time(e1) / 10
-                for name, outs in (("obs(r,norm,Hpl)", (o_r.data_ptr(), o_n.data_ptr(), 0, 0, 0, 0, o_Hpl.data_ptr())),
-                                   ("pose(Hpp,bp)", (0, 0, o_Hpp.data_ptr(), o_bp.data_ptr(), 0, 0, 0)),
-                                   ("point(Hll,bl)", (0, 0, 0, 0, o_Hll.data_ptr(), o_bl.data_ptr(), 0))):
-                    e0.record(side)
-                    for _ in range(10):
-                        plan.run_device(t_p.data_ptr(), t_x.data_ptr(), t_uv.data_ptr(), pr["K"], *outs, stream=side.cuda_stream)
-                    e1.record(side)
-                    side.synchronize()
-                    kb[name] = e0.elapsed_time(e1) / 10
             a_ba = ba_bytes / (kb["whole_pass"] * 1e-3) / 1e9
             ba_out["roofline"] = {"bound": "hbm", "achieved": round(a_ba, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(a_ba / HBM_PEAK_GBS, 4),
                                   "bytes_per_pass": int(ba_bytes), "device_ms_per_pass": round(kb["whole_pass"], 5),
-                                  "device_ms_by_outputs": {k: round(v, 5) for k, v in kb.items() if k != "whole_pass"},
-                                  "note": "HIP events on the launch stream, 10 passes back to back; ms_per_pass above is host wall clock per synchronous call (+ the all-reduce at N > 1)"}
+                                  "note": "HIP events on the launch stream, 10 passes back to back (k_ba_rot + k_ba_pass per pass; kernel durations: profiles/r3_*_ba_kernel_stats.csv); ms_per_pass above is host wall clock per synchronous call (+ the all-reduce at N > 1)"}
         plan.close()
 
     cpu = None
