@@ -17,6 +17,7 @@
 #include <cfloat>
 #include <cmath>
 #include <cstdlib>
+#include <utility>
 
 #include "vo_internal.h"
 
@@ -141,30 +142,111 @@ __device__ void svd_square(const double* A, double* W, double* U, double* Vt) {
 }
 
 // ------------------------------------------------------------------ polynomials in (x,y,z), degree <= 3
-// c[i][j][k] multiplies x^i y^j z^k; only the 20 entries with i + j + k <= 3 exist (the others are never written or read)
-struct Poly3 { double c[4][4][4]; };
-__device__ void pzero(Poly3& r) {
-    for (int i = 0; i < 4; i++) for (int j = 0; i + j < 4; j++) for (int k = 0; i + j + k < 4; k++) r.c[i][j][k] = 0;
-}
-// r = a*b (degrees da, db)
-__device__ void pmul(Poly3& r, const Poly3& a, int da, const Poly3& b, int db) {
-    pzero(r);
-    for (int i = 0; i <= da; i++)
-        for (int j = 0; i + j <= da; j++)
-            for (int k = 0; i + j + k <= da; k++) {
-                const double av = a.c[i][j][k];
-                if (av == 0) continue;
-                for (int p = 0; p <= db; p++)
-                    for (int q = 0; p + q <= db; q++)
-                        for (int s = 0; p + q + s <= db; s++) r.c[i + p][j + q][k + s] += av * b.c[p][q][s];
+// Compact forms: a polynomial of degree <= D holds exactly its (D+1)(D+2)(D+3)/6 coefficients (4 / 10 / 20), in the order
+// the nested loops "for i, for j, for k with i + j + k <= D" visit x^i y^j z^k.  Every loop over monomials is a compile-time
+// loop (sfor), so every coefficient access is a constant index and the polynomials live in registers.  (Until round 3 a
+// polynomial was a double[4][4][4] walked with run-time bounds: 29 of them, 15 KB of private memory per lane, and 239 MB of
+// scratch writes per launch of 1024 hypotheses.)  The arithmetic is the one of the loops it replaces, term by term and in
+// the same order; the loops skipped a term whose left coefficient was exactly 0, which only differs from adding it when
+// the right coefficient is not finite (0 * inf): the null-space vectors these are built from have unit norm.
+template <int... Is, class F>
+__device__ __forceinline__ void sfor_impl(std::integer_sequence<int, Is...>, F&& f) { (f(std::integral_constant<int, Is>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void sfor(F&& f) { sfor_impl(std::make_integer_sequence<int, N>{}, f); }
+
+struct Mono { int i, j, k; };
+constexpr int poly_size(int D) { return (D + 1) * (D + 2) * (D + 3) / 6; }
+template <int D>
+constexpr Mono mono_of(int n) {
+    int m = 0;
+    for (int i = 0; i <= D; i++)
+        for (int j = 0; i + j <= D; j++)
+            for (int k = 0; i + j + k <= D; k++) {
+                if (m == n) return Mono{i, j, k};
+                m++;
             }
+    return Mono{-1, -1, -1};
 }
-// r = a + sb*b
-__device__ void padd(Poly3& r, const Poly3& a, const Poly3& b, double sb) {
-    for (int i = 0; i < 4; i++) for (int j = 0; i + j < 4; j++) for (int k = 0; i + j + k < 4; k++) r.c[i][j][k] = a.c[i][j][k] + sb * b.c[i][j][k];
+template <int D>
+constexpr int mono_idx(int i, int j, int k) {
+    int m = 0;
+    for (int a = 0; a <= D; a++)
+        for (int b = 0; a + b <= D; b++)
+            for (int c = 0; a + b + c <= D; c++) {
+                if (a == i && b == j && c == k) return m;
+                m++;
+            }
+    return -1;
 }
-__constant__ signed char c_mono[20][3] = {{3, 0, 0}, {0, 3, 0}, {2, 1, 0}, {1, 2, 0}, {2, 0, 1}, {2, 0, 0}, {0, 2, 1}, {0, 2, 0}, {1, 1, 1}, {1, 1, 0},
-                                          {1, 0, 2}, {1, 0, 1}, {1, 0, 0}, {0, 1, 2}, {0, 1, 1}, {0, 1, 0}, {0, 0, 3}, {0, 0, 2}, {0, 0, 1}, {0, 0, 0}};
+template <int D>
+struct Poly { static constexpr int N = poly_size(D); double c[N]; };
+
+template <int D>
+__device__ __forceinline__ void pzero(Poly<D>& r) { sfor<Poly<D>::N>([&](auto I) { r.c[I] = 0; }); }
+// r = a * b
+template <int DA, int DB>
+__device__ __forceinline__ void pmul(Poly<DA + DB>& r, const Poly<DA>& a, const Poly<DB>& b) {
+    pzero(r);
+    sfor<Poly<DA>::N>([&](auto I) {
+        constexpr Mono ma = mono_of<DA>(I);
+        const double av = a.c[I];
+        sfor<Poly<DB>::N>([&](auto J) {
+            constexpr Mono mb = mono_of<DB>(J);
+            constexpr int o = mono_idx<DA + DB>(ma.i + mb.i, ma.j + mb.j, ma.k + mb.k);
+            r.c[o] += av * b.c[J];
+        });
+    });
+}
+// r = a + sb * b (r may be a)
+template <int D>
+__device__ __forceinline__ void padd(Poly<D>& r, const Poly<D>& a, const Poly<D>& b, double sb) {
+    sfor<Poly<D>::N>([&](auto I) { r.c[I] = a.c[I] + sb * b.c[I]; });
+}
+// the linear polynomial E0 x + E1 y + E2 z + E3 of one entry of the null-space basis (row-major 3x3 matrices, 9 apart)
+__device__ __forceinline__ Poly<1> plin(double e0, double e1, double e2, double e3) {
+    Poly<1> r;
+    r.c[mono_idx<1>(1, 0, 0)] = e0; r.c[mono_idx<1>(0, 1, 0)] = e1; r.c[mono_idx<1>(0, 0, 1)] = e2; r.c[mono_idx<1>(0, 0, 0)] = e3;
+    return r;
+}
+// the 20 monomials in the column order of the 10 x 20 constraint matrix
+constexpr int c_mono[20][3] = {{3, 0, 0}, {0, 3, 0}, {2, 1, 0}, {1, 2, 0}, {2, 0, 1}, {2, 0, 0}, {0, 2, 1}, {0, 2, 0}, {1, 1, 1}, {1, 1, 0},
+                               {1, 0, 2}, {1, 0, 1}, {1, 0, 0}, {0, 1, 2}, {0, 1, 1}, {0, 1, 0}, {0, 0, 3}, {0, 0, 2}, {0, 0, 1}, {0, 0, 0}};
+// q's coefficients as a row of that matrix
+template <class ROW>
+__device__ __forceinline__ void poly_to_row(const Poly<3>& q, ROW&& row) {
+    sfor<20>([&](auto M) { row[M] = q.c[mono_idx<3>(c_mono[M][0], c_mono[M][1], c_mono[M][2])]; });
+}
+// det(E) = 0 as a cubic: E rows given as linear polynomials
+__device__ __forceinline__ void poly_det(Poly<3>& d, const Poly<1> (&E)[3][3]) {
+    Poly<2> tmp, tmp2, m0, m1, m2;
+    Poly<3> t3;
+    pmul<1, 1>(tmp, E[1][1], E[2][2]); pmul<1, 1>(tmp2, E[1][2], E[2][1]); padd(m0, tmp, tmp2, -1.0);
+    pmul<1, 1>(tmp, E[1][0], E[2][2]); pmul<1, 1>(tmp2, E[1][2], E[2][0]); padd(m1, tmp, tmp2, -1.0);
+    pmul<1, 1>(tmp, E[1][0], E[2][1]); pmul<1, 1>(tmp2, E[1][1], E[2][0]); padd(m2, tmp, tmp2, -1.0);
+    pmul<1, 2>(d, E[0][0], m0);
+    pmul<1, 2>(t3, E[0][1], m1); padd(d, d, t3, -1.0);
+    pmul<1, 2>(t3, E[0][2], m2); padd(d, d, t3, 1.0);
+}
+// entry (r, c') of E E^T: sum_k Er[k] * Ec[k] over two rows of E
+__device__ __forceinline__ void poly_eet(Poly<2>& s, const Poly<1> (&Er)[3], const Poly<1> (&Ec)[3]) {
+    Poly<2> tmp;
+    pzero(s);
+    sfor<3>([&](auto K) {
+        pmul<1, 1>(tmp, Er[K], Ec[K]);
+        padd(s, s, tmp, 1.0);
+    });
+}
+// entry (r, c) of 2 E E^T E - trace(E E^T) E: EEr = row r of E E^T, Ecol = column c of E, Erc = E[r][c]
+__device__ __forceinline__ void poly_trace_eq(Poly<3>& q, const Poly<2> (&EEr)[3], const Poly<1> (&Ecol)[3], const Poly<2>& tr, const Poly<1>& Erc) {
+    Poly<3> tmp;
+    pzero(q);
+    sfor<3>([&](auto K) {
+        pmul<2, 1>(tmp, EEr[K], Ecol[K]);
+        padd(q, q, tmp, 2.0);
+    });
+    pmul<2, 1>(tmp, tr, Erc);
+    padd(q, q, tmp, -1.0);
+}
 
 struct Cx { double re, im; };
 __device__ __forceinline__ Cx cmul(Cx a, Cx b) { return Cx{a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
@@ -544,57 +626,27 @@ __device__ int five_point(const double* x1, const double* x2, double* Ebuf, cons
     const double* EE0 = At + 5 * 9;  // 4 null-space vectors, consecutive rows
     FP_TICK(1);
 
-    Poly3 Ep[3][3];
-    for (int r = 0; r < 3; r++)
-        for (int c = 0; c < 3; c++) {
-            pzero(Ep[r][c]);
-            Ep[r][c].c[1][0][0] = EE0[0 * 9 + r * 3 + c];
-            Ep[r][c].c[0][1][0] = EE0[1 * 9 + r * 3 + c];
-            Ep[r][c].c[0][0][1] = EE0[2 * 9 + r * 3 + c];
-            Ep[r][c].c[0][0][0] = EE0[3 * 9 + r * 3 + c];
-        }
-    Poly3 EEt[3][3], tmp, tmp2;
-    for (int r = 0; r < 3; r++)
-        for (int c = 0; c < 3; c++) {
-            Poly3 s;
-            pzero(s);
-            for (int k = 0; k < 3; k++) {
-                pmul(tmp, Ep[r][k], 1, Ep[c][k], 1);
-                padd(s, s, tmp, 1.0);
-            }
-            EEt[r][c] = s;
-        }
-    Poly3 tr;
-    padd(tr, EEt[0][0], EEt[1][1], 1.0);
-    padd(tr, tr, EEt[2][2], 1.0);
+    Poly<1> Ep[3][3];
+    sfor<9>([&](auto I) { Ep[I / 3][I % 3] = plin(EE0[0 * 9 + I], EE0[1 * 9 + I], EE0[2 * 9 + I], EE0[3 * 9 + I]); });
     double A[10][20];          // one-lane form: the 10 x 20 constraint matrix
     double Afin[6][10];        // 16-lane form: rows 4..9, columns 10..19 after the elimination (all that is read afterwards)
     if (!WIDE) {
-        auto store_eq = [&](int e, const Poly3& q) {
-            for (int m = 0; m < 20; m++) A[e][m] = q.c[c_mono[m][0]][c_mono[m][1]][c_mono[m][2]];
-        };
+        Poly<2> EEt[3][3], tr;
+        sfor<9>([&](auto I) { poly_eet(EEt[I / 3][I % 3], Ep[I / 3], Ep[I % 3]); });
+        padd(tr, EEt[0][0], EEt[1][1], 1.0);
+        padd(tr, tr, EEt[2][2], 1.0);
         {
-            Poly3 m0, m1, m2, d;
-            pmul(tmp, Ep[1][1], 1, Ep[2][2], 1); pmul(tmp2, Ep[1][2], 1, Ep[2][1], 1); padd(m0, tmp, tmp2, -1.0);
-            pmul(tmp, Ep[1][0], 1, Ep[2][2], 1); pmul(tmp2, Ep[1][2], 1, Ep[2][0], 1); padd(m1, tmp, tmp2, -1.0);
-            pmul(tmp, Ep[1][0], 1, Ep[2][1], 1); pmul(tmp2, Ep[1][1], 1, Ep[2][0], 1); padd(m2, tmp, tmp2, -1.0);
-            pmul(d, Ep[0][0], 1, m0, 2);
-            pmul(tmp, Ep[0][1], 1, m1, 2); padd(d, d, tmp, -1.0);
-            pmul(tmp, Ep[0][2], 1, m2, 2); padd(d, d, tmp, 1.0);
-            store_eq(0, d);
+            Poly<3> d;
+            poly_det(d, Ep);
+            poly_to_row(d, A[0]);
         }
-        for (int r = 0; r < 3; r++)
-            for (int c = 0; c < 3; c++) {
-                Poly3 s;
-                pzero(s);
-                for (int k = 0; k < 3; k++) {
-                    pmul(tmp, EEt[r][k], 2, Ep[k][c], 1);
-                    padd(s, s, tmp, 2.0);
-                }
-                pmul(tmp, tr, 2, Ep[r][c], 1);
-                padd(s, s, tmp, -1.0);
-                store_eq(1 + r * 3 + c, s);
-            }
+        sfor<9>([&](auto I) {
+            constexpr int r = I / 3, c = I % 3;
+            const Poly<1> Ecol[3] = {Ep[0][c], Ep[1][c], Ep[2][c]};
+            Poly<3> q;
+            poly_trace_eq(q, EEt[r], Ecol, tr, Ep[r][c]);
+            poly_to_row(q, A[1 + I]);
+        });
         FP_TICK(2);
         // Gauss-Jordan with partial pivoting.  A lives in private memory, where a dependent access costs a round trip of several
         // hundred cycles, and the loop as OpenCV writes it is one such round trip per element (300 us of the solver's 420 us outside the
@@ -653,27 +705,26 @@ __device__ int five_point(const double* x1, const double* x2, double* Ebuf, cons
         const int k = sub < 10 ? sub : 9;          // lanes 10..15 shadow lane 9
         double row[20];
         {
-            Poly3 q;
-            if (k == 0) {
-                Poly3 m0, m1, m2;
-                pmul(tmp, Ep[1][1], 1, Ep[2][2], 1); pmul(tmp2, Ep[1][2], 1, Ep[2][1], 1); padd(m0, tmp, tmp2, -1.0);
-                pmul(tmp, Ep[1][0], 1, Ep[2][2], 1); pmul(tmp2, Ep[1][2], 1, Ep[2][0], 1); padd(m1, tmp, tmp2, -1.0);
-                pmul(tmp, Ep[1][0], 1, Ep[2][1], 1); pmul(tmp2, Ep[1][1], 1, Ep[2][0], 1); padd(m2, tmp, tmp2, -1.0);
-                pmul(q, Ep[0][0], 1, m0, 2);
-                pmul(tmp, Ep[0][1], 1, m1, 2); padd(q, q, tmp, -1.0);
-                pmul(tmp, Ep[0][2], 1, m2, 2); padd(q, q, tmp, 1.0);
-            } else {
-                const int r = (k - 1) / 3, c = (k - 1) - 3 * r;
-                pzero(q);
-                for (int kk = 0; kk < 3; kk++) {
-                    pmul(tmp, EEt[r][kk], 2, Ep[kk][c], 1);
-                    padd(q, q, tmp, 2.0);
-                }
-                pmul(tmp, tr, 2, Ep[r][c], 1);
-                padd(q, q, tmp, -1.0);
-            }
-#pragma unroll
-            for (int m = 0; m < 20; m++) row[m] = q.c[c_mono[m][0]][c_mono[m][1]][c_mono[m][2]];
+            // lane k > 0 expands constraint (r, c) = ((k - 1) / 3, (k - 1) % 3): it needs row r of E E^T (made here from row r of
+            // E, picked by selects: no lane-dependent indexing) and the diagonal of E E^T for the trace; lane 0 expands det(E)
+            const int kk = k > 0 ? k - 1 : 0;
+            const int r = kk / 3, c = kk - 3 * r;
+            auto pick = [&](const Poly<1>& p0, const Poly<1>& p1, const Poly<1>& p2, int w) {
+                Poly<1> o;
+                sfor<4>([&](auto I) { o.c[I] = w == 0 ? p0.c[I] : (w == 1 ? p1.c[I] : p2.c[I]); });
+                return o;
+            };
+            const Poly<1> Er[3] = {pick(Ep[0][0], Ep[1][0], Ep[2][0], r), pick(Ep[0][1], Ep[1][1], Ep[2][1], r), pick(Ep[0][2], Ep[1][2], Ep[2][2], r)};
+            const Poly<1> Ecol[3] = {pick(Ep[0][0], Ep[0][1], Ep[0][2], c), pick(Ep[1][0], Ep[1][1], Ep[1][2], c), pick(Ep[2][0], Ep[2][1], Ep[2][2], c)};
+            Poly<2> EEr[3], d0, d1, d2, tr;
+            sfor<3>([&](auto K) { poly_eet(EEr[K], Er, Ep[K]); });
+            poly_eet(d0, Ep[0], Ep[0]); poly_eet(d1, Ep[1], Ep[1]); poly_eet(d2, Ep[2], Ep[2]);
+            padd(tr, d0, d1, 1.0);
+            padd(tr, tr, d2, 1.0);
+            Poly<3> q;
+            poly_trace_eq(q, EEr, Ecol, tr, pick(Er[0], Er[1], Er[2], c));
+            if (k == 0) poly_det(q, Ep);
+            poly_to_row(q, row);
         }
         FP_TICK(2);
         // Gauss-Jordan with the matrix row `lid` in this lane (a row swap exchanges the two lanes' lids, not their data)
@@ -791,10 +842,19 @@ __device__ int five_point(const double* x1, const double* x2, double* Ebuf, cons
         for (int k = 0; k < 9; k++) E[k] /= nrm;
         return true;
     };
+    // Ebuf may be global memory (the solve kernels hand in the hypothesis' slot of the model table): a model is finished in
+    // registers and stored once
     int count = 0;
     if (!WIDE) {
-        for (int i = 0; i < 10; i++)
-            if (model_of_root(rre[i], rim[i], Ebuf + count * 9)) count++;
+#pragma unroll
+        for (int i = 0; i < 10; i++) {
+            double Em[9];
+            if (model_of_root(rre[i], rim[i], Em)) {
+#pragma unroll
+                for (int j = 0; j < 9; j++) Ebuf[count * 9 + j] = Em[j];
+                count++;
+            }
+        }
     } else {
         // 16 lanes: lane k < 10 takes root k, then the models are collected in root order along the row (lanes 10..15 shadow lane 9)
         const int k = sub < 10 ? sub : 9;
@@ -803,7 +863,10 @@ __device__ int five_point(const double* x1, const double* x2, double* Ebuf, cons
         const int mine = model_of_root(rre[k], rim[k], Em) ? 1 : 0;
 #define FP_COLLECT(I)                                                                                       \
         if (__builtin_amdgcn_mov_dpp(mine, 0x150 + I, 0xf, 0xf, true)) {                                    \
-            for (int j = 0; j < 9; j++) Ebuf[count * 9 + j] = row_bcast<I>(Em[j]);                          \
+            for (int j = 0; j < 9; j++) {                                                                   \
+                const double ev = row_bcast<I>(Em[j]);                                                      \
+                if (sub == 0) Ebuf[count * 9 + j] = ev;                                                     \
+            }                                                                                               \
             count++;                                                                                        \
         }
         FP_COLLECT(0) FP_COLLECT(1) FP_COLLECT(2) FP_COLLECT(3) FP_COLLECT(4)
@@ -906,11 +969,7 @@ __global__ __launch_bounds__(DK_T) void k_ransac_solve(const PoseWork* __restric
         norm_pt(nk, q1[o], x1[2 * i], x1[2 * i + 1]);
         norm_pt(nk, q2[o], x2[2 * i], x2[2 * i + 1]);
     }
-    double Eb[90];
-    const int nm = five_point<false>(x1, x2, Eb);
-    nmodels[ho] = nm;
-    double* mo = models + ho * 90;
-    for (int i = 0; i < nm * 9; i++) mo[i] = Eb[i];
+    nmodels[ho] = five_point<false>(x1, x2, models + ho * 90);
 }
 
 // The same with 16 lanes (one DPP row) per hypothesis, for rounds with few hypotheses in total: the serial chain of a
@@ -932,12 +991,8 @@ __global__ __launch_bounds__(DK_T) void k_ransac_solve_wide(const PoseWork* __re
         norm_pt(nk, q1[o], x1[2 * i], x1[2 * i + 1]);
         norm_pt(nk, q2[o], x2[2 * i], x2[2 * i + 1]);
     }
-    double Eb[90];
-    const int nm = five_point<true>(x1, x2, Eb, sub);
-    if (sub != 0) return;
-    nmodels[ho] = nm;
-    double* mo = models + ho * 90;
-    for (int i = 0; i < nm * 9; i++) mo[i] = Eb[i];
+    const int nm = five_point<true>(x1, x2, models + ho * 90, sub);
+    if (sub == 0) nmodels[ho] = nm;
 }
 
 // one wavefront per (pair, hypothesis): inlier count of each of its models
