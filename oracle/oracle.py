@@ -169,6 +169,26 @@ def find_essential_ransac(q1, q2, K, prob=0.999, thr=1.0, max_iters=1000):
     return E, mask[:n].copy(), ninl.value, iters.value
 
 
+def set_pose_variant(hypot_mode=0, ainv_mode=0):
+    """Rounding variants of the pose side (process-wide, see vo_oracle.cpp): hypot_mode 1 = std::hypot in the Jacobi
+    rotations; ainv_mode 1 = LU inverse + matrix product for the 10 x 10 elimination.  (0, 0) = defaults = the HIP solver."""
+    lib().orc_set_pose_variant(int(hypot_mode), int(ainv_mode))
+
+
+class pose_variant:
+    """with oracle.pose_variant(hypot_mode=1): ...   (restores the defaults on exit)"""
+
+    def __init__(self, hypot_mode=0, ainv_mode=0):
+        self.v = (hypot_mode, ainv_mode)
+
+    def __enter__(self):
+        set_pose_variant(*self.v)
+        return self
+
+    def __exit__(self, *exc):
+        set_pose_variant(0, 0)
+
+
 def five_point(x1, x2):
     x1 = np.ascontiguousarray(x1, np.float64); x2 = np.ascontiguousarray(x2, np.float64)
     Eb = np.zeros((10, 3, 3))

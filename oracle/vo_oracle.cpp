@@ -20,6 +20,18 @@
 #include <cstring>
 #include <vector>
 
+/* Pose-side rounding variants (pin-readiness: tests/test_zz_live_cv2.py enumerates them against a live cv2; the defaults are
+ * what the HIP solver implements).  Process-wide switches, set through orc_set_pose_variant before calling; not meant to
+ * be flipped while other threads run the solver.
+ *   hypot_mode 0: the Jacobi rotation's gamma = sqrt(p*p + beta*beta) (default); 1: std::hypot(p, beta), as OpenCV's
+ *                 JacobiSVDImpl_ writes it
+ *   ainv_mode  0: A[:, :10]^-1 A[:, 10:] by Gauss-Jordan on the augmented 10 x 20 matrix (default);
+ *              1: what `A.colRange(0, 10).inv() * A.colRange(10, 20)` does in OpenCV: Mat::inv(DECOMP_LU) = LU with partial
+ *                 pivoting applied to an identity right-hand side and back-substituted (hal::LU64f), then a matrix product
+ *                 whose every entry is a row x column sum in ascending k */
+#include <atomic>
+static std::atomic<int> g_pose_hypot_mode{0}, g_pose_ainv_mode{0};
+
 namespace {
 
 /* ---------------------------------------------------------------- rounding helpers */
@@ -418,7 +430,7 @@ void jacobi_svd(double* At, int astep, double* W, double* Vt, int vstep, int m, 
                 for (k = 0; k < m; k++) p += Ai[k] * Aj[k];
                 if (std::fabs(p) <= eps * std::sqrt(a * b)) continue;
                 p *= 2;
-                double beta = a - b, gamma = std::sqrt(p * p + beta * beta);
+                double beta = a - b, gamma = g_pose_hypot_mode.load() ? std::hypot(p, beta) : std::sqrt(p * p + beta * beta);
                 if (beta < 0) {
                     double delta = (gamma - beta) * 0.5;
                     s = std::sqrt(delta / gamma);
@@ -681,6 +693,48 @@ int five_point(const double* x1, const double* x2, double* Ebuf) {
     double A[10][20];
     for (int e = 0; e < 10; e++)
         for (int m = 0; m < 20; m++) A[e][m] = eq[e].c[kMono[m][0]][kMono[m][1]][kMono[m][2]];
+    if (g_pose_ainv_mode.load() == 1) {
+        /* hal::LU64f (LUImpl<double>, eps = DBL_EPSILON * 100) on a copy of the left block with B = I, then the product */
+        double L[10][10], X[10][10], R[10][10];
+        for (int i = 0; i < 10; i++)
+            for (int j = 0; j < 10; j++) { L[i][j] = A[i][j]; X[i][j] = i == j ? 1.0 : 0.0; }
+        bool ok = true;
+        for (int i = 0; i < 10 && ok; i++) {
+            int k = i;
+            for (int j = i + 1; j < 10; j++)
+                if (std::fabs(L[j][i]) > std::fabs(L[k][i])) k = j;
+            if (std::fabs(L[k][i]) < DBL_EPSILON * 100) { ok = false; break; }
+            if (k != i) {
+                for (int j = i; j < 10; j++) std::swap(L[i][j], L[k][j]);
+                for (int j = 0; j < 10; j++) std::swap(X[i][j], X[k][j]);
+            }
+            const double d = -1 / L[i][i];
+            for (int j = i + 1; j < 10; j++) {
+                const double alpha = L[j][i] * d;
+                for (int kk = i + 1; kk < 10; kk++) L[j][kk] += alpha * L[i][kk];
+                for (int kk = 0; kk < 10; kk++) X[j][kk] += alpha * X[i][kk];
+            }
+        }
+        if (ok) {
+            for (int i = 9; i >= 0; i--)
+                for (int j = 0; j < 10; j++) {
+                    double sum = X[i][j];
+                    for (int kk = i + 1; kk < 10; kk++) sum -= L[i][kk] * X[kk][j];
+                    X[i][j] = sum / L[i][i];
+                }
+        } else {
+            for (int i = 0; i < 10; i++)
+                for (int j = 0; j < 10; j++) X[i][j] = 0;      /* Mat::inv of a singular matrix: the zero matrix */
+        }
+        for (int i = 0; i < 10; i++)
+            for (int j = 0; j < 10; j++) {
+                double sum = 0;
+                for (int kk = 0; kk < 10; kk++) sum += X[i][kk] * A[kk][10 + j];
+                R[i][j] = sum;
+            }
+        for (int i = 0; i < 10; i++)
+            for (int j = 0; j < 10; j++) A[i][10 + j] = R[i][j];
+    } else
     /* A = inv(A[:, :10]) * A[:, 10:]  by Gauss-Jordan with partial pivoting */
     for (int col = 0; col < 10; col++) {
         int piv = col;
@@ -1159,6 +1213,11 @@ int orc_retain_best(const float* keys, int n, int n_points, int32_t* out_idx, in
     for (size_t i = 0; i < v.size(); i++) out_idx[i] = v[i].idx;
     *n_out = (int)v.size();
     return 0;
+}
+
+void orc_set_pose_variant(int hypot_mode, int ainv_mode) {
+    g_pose_hypot_mode.store(hypot_mode ? 1 : 0);
+    g_pose_ainv_mode.store(ainv_mode ? 1 : 0);
 }
 
 }  // extern "C"

@@ -97,6 +97,10 @@ int orc_five_point(const double* x1, const double* x2, double* Ebuf);
 /* cv::solvePoly on a degree-10 coefficient vector (ascending powers); roots as (re, im) pairs */
 int orc_solve_poly10(const double* coeffs, double* roots_re_im);
 
+/* Rounding variants of the pose side (process-wide; defaults 0, 0 = what the HIP solver implements): hypot_mode 1 = std::hypot in
+ * the Jacobi rotations, ainv_mode 1 = LU inverse + matrix product for the 10 x 10 elimination (see vo_oracle.cpp). */
+void orc_set_pose_variant(int hypot_mode, int ainv_mode);
+
 /* cv::recoverPose(E, q1, q2, K, R, t) -- no input mask, distanceThresh given. */
 int orc_recover_pose(const double E[9], const float* q1, const float* q2, int n, const double K[9],
                      double dist_thresh, double R[9], double t[3], int* n_good);

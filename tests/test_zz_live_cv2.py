@@ -69,10 +69,22 @@ def _matched_points(oracle, a, b):
 
 
 def test_find_essential_and_recover_pose(oracle, kitti02, K02):
+    """findEssentialMat against the oracle's pose-side rounding variants (hypot_mode x ainv_mode, oracle.set_pose_variant):
+    the tuples that reproduce cv2's inlier mask and E are printed, exactly as the ORB test does for its flags; the HIP
+    solver implements (0, 0) and follows whichever tuple a cv2 box names."""
     q1, q2 = _matched_points(oracle, kitti02[0], kitti02[1])
     E, mask = cv2.findEssentialMat(q1, q2, K02, cv2.RANSAC, 0.999, 1.0, None)     # libs/vo_utils.py:141
+    ok, bits = [], []
+    for hm, am in itertools.product((0, 1), repeat=2):
+        with oracle.pose_variant(hypot_mode=hm, ainv_mode=am):
+            Ev, mv, _, _ = oracle.find_essential_ransac(q1, q2, K02)
+        if np.array_equal(mask.ravel().astype(bool), np.asarray(mv).ravel().astype(bool)) and np.abs(E - Ev).max() < 1e-9:
+            ok.append({"hypot_mode": hm, "ainv_mode": am})
+            if np.array_equal(E, Ev):
+                bits.append({"hypot_mode": hm, "ainv_mode": am})
+    print("cv2 %s: pose variants that reproduce findEssentialMat's mask and E (1e-9): %s; bit for bit: %s" % (cv2.__version__, ok or "none", bits or "none"))
     Eo, mo, no, _ = oracle.find_essential_ransac(q1, q2, K02)
-    assert np.array_equal(mask.ravel().astype(bool), np.asarray(mo).ravel().astype(bool))
+    assert np.array_equal(mask.ravel().astype(bool), np.asarray(mo).ravel().astype(bool)), "defaults differ; variants that match: %s" % (ok or "none")
     assert np.abs(E - Eo).max() < 1e-9
     _, R, t, _ = cv2.recoverPose(E, q1, q2, K02, mask)                             # libs/vo_utils.py:143
     Ro, to, go = oracle.recover_pose(E, q1, q2, K02)
