@@ -298,6 +298,15 @@ __device__ __forceinline__ int fast_arc_extreme(const uint8_t* p) {
 // byte k (0..3) of dword d
 #define BYTE(d, k) (((d) >> (8 * (k))) & 0xFFu)
 
+// per byte max(x - t, 0): the bytes as two pairs of 16-bit fields, v_pk_sub_u16 with clamp; T2 = t | t << 16
+typedef unsigned short fast_u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t fast_sat_sub_bytes(uint32_t x, uint32_t T2) {
+    const fast_u16x2 t = __builtin_bit_cast(fast_u16x2, T2);
+    const uint32_t e = __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(__builtin_bit_cast(fast_u16x2, x & 0x00FF00FFu), t));
+    const uint32_t o = __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(__builtin_bit_cast(fast_u16x2, (x >> 8) & 0x00FF00FFu), t));
+    return e | (o << 8);
+}
+
 // inclusive prefix sum over the 64 lanes of a wavefront with DPP row shifts / row broadcasts (6 VALU ops)
 __device__ __forceinline__ int wave_incl_scan(int v) {
     v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);  // row_shr:1
@@ -390,6 +399,12 @@ __global__ __launch_bounds__(256) void k_fast_tiles(const Geom* __restrict__ g, 
     // wavefronts; one LDS atomic per wavefront and iteration reserves the queue space.
     const int cmax = min(VO_TILE_W + 2, Lw - 3 - (x0 - 1));   // FAST is defined 3 px inside the level
     const int rmax = Lh - 3 - (y0 - 1);
+#ifndef VO_FAST_MINMAX_PRETEST
+    const uint32_t T2 = (uint32_t)thr | ((uint32_t)thr << 16);
+    // bit 7 of byte i set iff position k4 + i of this lane's run is a position of the level (the row test is made per iteration)
+    const int nval = min(max(cmax - (int)((tid & 15) * 4), 0), 4);
+    const uint32_t colmask = nval >= 4 ? 0x80808080u : (0x80808080u & ((1u << (8 * nval)) - 1u));
+#endif
 #pragma unroll
     for (int it = 0; it < 2; it++) {
         // 16 runs of 4 positions per row, 16 rows per iteration.  The two rows that share a half-wavefront (32 lanes = one LDS
@@ -406,6 +421,7 @@ __global__ __launch_bounds__(256) void k_fast_tiles(const Geom* __restrict__ g, 
         const uint32_t P21 = rowP2[1], P22 = rowP2[2], M21 = rowM2[1], M22 = rowM2[2];
         const uint32_t P31 = rowP3[1], P32 = rowP3[2], M31 = rowM3[1], M32 = rowM3[2];
         *reinterpret_cast<uint32_t*>(&sc[r * SCP + k4]) = 0;
+#ifdef VO_FAST_MINMAX_PRETEST
         // position i: centre = LDS col k4+6+i;  mm = min over pairs of max, xm = max over pairs of min
 #define PRETEST(i, v, a0, a8, a2, a10, a4, a12, a6, a14)                                                             \
         const int mm##i = (int)min(min(max(a0, a8), max(a2, a10)), min(max(a4, a12), max(a6, a14)));                  \
@@ -418,6 +434,41 @@ __global__ __launch_bounds__(256) void k_fast_tiles(const Geom* __restrict__ g, 
         PRETEST(2, BYTE(C2, 0), BYTE(P32, 0), BYTE(M32, 0), BYTE(P22, 2), BYTE(M21, 2), BYTE(C2, 3), BYTE(C1, 1), BYTE(M22, 2), BYTE(P21, 2))
         PRETEST(3, BYTE(C2, 1), BYTE(P32, 1), BYTE(M32, 1), BYTE(P22, 3), BYTE(M21, 3), BYTE(C3, 0), BYTE(C1, 2), BYTE(M22, 3), BYTE(P21, 3))
 #undef PRETEST
+#else
+        // Byte-parallel form of the same test (round 3): the four positions of the lane are the four bytes of a dword, and
+        // v_lerp_u8 -- per byte (a + b + c) >> 1 on a 9-bit sum -- is a per-byte unsigned compare: bit 7 of lerp(a, ~b, 0) is
+        // a > b, bit 7 of lerp(a, ~b, 1) is a >= b.  Per pixel window (the circle pixel k of all four positions, one aligned
+        // dword or one v_alignbit of two) that is ONE instruction for four "p_k > v + t" and one for four "p_k >= v - t",
+        // where the min / max form spent 12 SDWA min / max per POSITION; the pair logic is plain and / or on the bit-7 lanes.
+        // Thresholds per byte: nvt = 255 - min(v + t, 255) and nvmt = 255 - max(v - t, 0) (saturating 16-bit-field
+        // subtractions, once per centre dword), so "never" cases (v + t > 255, v - t < 0) come out false by themselves.
+        uint32_t Rb, Rd;
+        {
+            const uint32_t V = __builtin_amdgcn_alignbit(C2, C1, 16);
+            const uint32_t nV = ~V;
+            const uint32_t nvt = fast_sat_sub_bytes(nV, T2);
+            const uint32_t nvmt = ~fast_sat_sub_bytes(V, T2);
+            const uint32_t a0 = __builtin_amdgcn_alignbit(P32, P31, 16), a8 = __builtin_amdgcn_alignbit(M32, M31, 16);
+            const uint32_t a4 = __builtin_amdgcn_alignbit(C3, C2, 8), a12 = __builtin_amdgcn_alignbit(C1, C0, 24);
+            const uint32_t a2 = P22, a14 = P21, a6 = M22, a10 = M21;
+#define BR(a) __builtin_amdgcn_lerp((a), nvt, 0u)              /* bit 7: a > v + t */
+#define NL(a) __builtin_amdgcn_lerp((a), nvmt, 0x01010101u)    /* bit 7: a >= v - t, i.e. NOT darker */
+            const uint32_t vm = r < rmax ? colmask : 0u;
+            // (adding the two odd pairs (1, 9), (7, 15), whose pixels lie in the row +-3 dwords loaded anyway, measured SLOWER: 161
+            // against 155 us per launch -- 16 more VALU instructions per run of 4, and only a few per cent fewer survivors)
+            Rb = (BR(a0) | BR(a8)) & (BR(a2) | BR(a10)) & (BR(a4) | BR(a12)) & (BR(a6) | BR(a14)) & vm;
+            Rd = ~((NL(a0) & NL(a8)) | (NL(a2) & NL(a10)) | (NL(a4) & NL(a12)) | (NL(a6) & NL(a14))) & vm;
+#undef BR
+#undef NL
+        }
+        // opaque to the optimiser from here: otherwise every use of a position's predicate (its ballot, its queue write) is
+        // re-derived from the pair terms with a bit-select of its own
+        asm volatile("" : "+v"(Rb), "+v"(Rd));
+        const bool pb0 = BYTE(Rb, 0) != 0, pb1 = BYTE(Rb, 1) != 0, pb2 = BYTE(Rb, 2) != 0, pb3 = BYTE(Rb, 3) != 0;
+        const bool pd0 = BYTE(Rd, 0) != 0, pd1 = BYTE(Rd, 1) != 0, pd2 = BYTE(Rd, 2) != 0, pd3 = BYTE(Rd, 3) != 0;
+        const unsigned long long mb0 = __ballot(pb0), mb1 = __ballot(pb1), mb2 = __ballot(pb2), mb3 = __ballot(pb3);
+        const unsigned long long md0 = __ballot(pd0), md1 = __ballot(pd1), md2 = __ballot(pd2), md3 = __ballot(pd3);
+#endif
         const int nb0 = (int)__popcll(mb0), nb1 = (int)__popcll(mb1), nb2 = (int)__popcll(mb2), nb3 = (int)__popcll(mb3);
         const int nd0 = (int)__popcll(md0), nd1 = (int)__popcll(md1), nd2 = (int)__popcll(md2), nd3 = (int)__popcll(md3);
         const int add = (nb0 + nb1 + nb2 + nb3) | ((nd0 + nd1 + nd2 + nd3) << 16);
@@ -476,8 +527,10 @@ __global__ __launch_bounds__(256) void k_fast_tiles(const Geom* __restrict__ g, 
         const int i = corner[q];
         const int r = i >> 6, c = i & 63;                      // score position; output (r-1, c-1)
         const uint8_t* s0 = &sc[i];
-        const int s = s0[0];
         const int xi = x0 - 1 + c, yi = y0 - 1 + r;
+        const int s = s0[0];
+        // (nine byte reads: reading the 3 x 3 neighbourhood as three UNALIGNED dwords measured slower, 161 against 156 us per
+        // launch -- misaligned LDS accesses stall the pipe)
         if (r >= 1 && r <= VO_TILE_H && c >= 1 && c <= VO_TILE_W && xi < Lw - VO_EDGE && yi < Lh - VO_EDGE &&
             s > s0[-1] && s > s0[1] && s > s0[-SCP - 1] && s > s0[-SCP] && s > s0[-SCP + 1] && s > s0[SCP - 1] && s > s0[SCP] && s > s0[SCP + 1])
             atomicOr(&bm[(r - 1) * 2 + ((c - 1) >> 5)], 1u << ((c - 1) & 31));
