@@ -67,3 +67,44 @@ def test_ba_config5_properties():
     assert (w > -1e-6 * np.abs(w).max()).all()
     w = np.linalg.eigvalsh(out["Hll"])
     assert (w > -1e-6 * np.abs(w).max()).all()
+
+
+def test_ba_point_sums_fused_and_separate_agree():
+    """Observations sorted by point take the fused path (point blocks summed inside the observation role, blocks cut at point
+    boundaries; points nobody observes are zeroed); the same problem with its observations shuffled, or with one point seen
+    more than 256 times, takes the separate point role.  Both must give the oracle's blocks, and for the same terms the
+    same bits (the sums run in observation order either way)."""
+    from oracle import ba_oracle as BO
+    from visual_slam_amd import ba
+    rng = np.random.default_rng(11)
+    P, N = 12, 400
+    poses = np.zeros((P, 6)); poses[:, :3] = rng.normal(0, 0.05, (P, 3)); poses[:, 3:] = rng.normal(0, 0.3, (P, 3))
+    pts = np.stack([rng.uniform(-3, 3, N), rng.uniform(-2, 2, N), rng.uniform(6, 30, N)], 1)
+    counts = rng.integers(0, 9, N); counts[7] = 0; counts[N - 1] = 0; counts[100] = 300          # unobserved points; one point > 256 later
+    K = np.array([[700.0, 0, 600], [0, 710.0, 180], [0, 0, 1]])
+
+    def problem(cnt):
+        op = np.repeat(np.arange(N, dtype=np.int32), cnt)
+        oj = rng.integers(0, P, len(op)).astype(np.int32)
+        uv = np.array([BO.project(poses[j], pts[i], K) for j, i in zip(oj, op)]) + rng.normal(0, 1, (len(op), 2))
+        return oj, op, uv
+
+    small = counts.copy(); small[100] = 5
+    for cnt in (small, counts):                      # fused; then not fusable (a point with 300 observations)
+        oj, op, uv = problem(cnt)
+        plan = ba.BAPlan(oj, op, P, N)
+        out = plan.run(poses, pts, uv, K)
+        plan.close()
+        ref = BO.ba_pass(poses, pts, oj, op, uv, K)
+        for k in ("r", "norm", "Hpl"):
+            assert _close(out[k], ref[k], 1e-12), k
+        for k in ("Hpp", "bp", "Hll", "bl"):
+            assert _close(out[k], ref[k], 1e-10), k
+        assert not out["Hll"][7].any() and not out["bl"][N - 1].any()
+        # shuffled observations: the separate point role; a point's terms are then summed in another order
+        perm = rng.permutation(len(op))
+        plan = ba.BAPlan(oj[perm], op[perm], P, N)
+        out2 = plan.run(poses, pts, uv[perm], K)
+        plan.close()
+        assert np.array_equal(out2["r"], out["r"][perm]) and np.array_equal(out2["Hpl"], out["Hpl"][perm])
+        assert _close(out2["Hll"], out["Hll"], 1e-12) and _close(out2["bl"], out["bl"], 1e-12) and _close(out2["Hpp"], out["Hpp"], 1e-12)

@@ -32,6 +32,9 @@ struct vo_ba_plan {
     int *d_pose_start = nullptr, *d_pose_obs = nullptr, *d_pose_pt = nullptr;        // observations grouped by pose (+ their point index)
     int *d_point_start = nullptr, *d_point_obs = nullptr, *d_point_pose = nullptr;   // observations grouped by point (+ their pose index)
     double* d_tab = nullptr;                                 // [P][BA_TAB]: R (9), t (3), W (9)
+    int *d_blk_start = nullptr, *d_empty = nullptr;          // observation blocks (<= 256 each); points nobody observes
+    int n_blk = 0, n_empty = 0;
+    bool fuse_points = false;                                // observations sorted by point, blocks cut at point boundaries
     double* d_work = nullptr;                                // staging for the host entry point
     size_t work_bytes = 0;
     hipStream_t stream = nullptr;
@@ -55,8 +58,14 @@ __device__ __forceinline__ void ba_rodrigues(const double* r, double R[9]) {
     R[6] = c1 * kx * kz - s * ky; R[7] = c1 * ky * kz + s * kx; R[8] = c + c1 * kz * kz;
 }
 
-__global__ __launch_bounds__(256) void k_ba_rot(int P, const double* __restrict__ poses, double* __restrict__ tab) {
+__global__ __launch_bounds__(256) void k_ba_rot(int P, const double* __restrict__ poses, double* __restrict__ tab, int n_empty,
+                                                const int* __restrict__ empty_points, double* __restrict__ Hll, double* __restrict__ bl) {
     const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j < n_empty) {   // points without observations: their blocks are zero, and (with the point sums fused into the observation role) no other lane writes them
+        const long i = empty_points[j];
+        if (Hll) for (int a = 0; a < 9; a++) Hll[i * 9 + a] = 0;
+        if (bl) for (int a = 0; a < 3; a++) bl[i * 3 + a] = 0;
+    }
     if (j >= P) return;
     const double* pose = poses + (long)j * 6;
     double R[9];
@@ -139,16 +148,27 @@ __device__ __forceinline__ void ba_jp(const BaPose& p, const double Y[3], const 
 }
 
 #define BA_HPL_PITCH 19   // doubles per lane in the LDS staging of Hpl (18 + 1: 38 dwords, so 16 lanes' 8-byte writes cover all 32 banks)
-__device__ __forceinline__ void ba_role_obs(double* sh, int blk, int M, const int* __restrict__ obs_pose, const int* __restrict__ obs_point,
-                                            const double* __restrict__ tab, const double* __restrict__ points,
+#define BA_PT_PITCH 13    // doubles per lane in the LDS staging of the point terms (12 + the point id: 26 dwords, conflict free like BA_HPL_PITCH)
+// One workgroup takes the observations [blk_start[blk], blk_start[blk + 1]) (at most 256).  With FUSE (the observations are
+// sorted by point and the plan cut the blocks at point boundaries) the workgroup also sums the point blocks Hll / bl of its
+// points: every lane stages its observation's 12 terms in LDS and the lane of a point's FIRST observation adds the run up in
+// observation order -- the order, and the bits, of the separate point role, which then has nothing left to do.
+template <bool FUSE>
+__device__ __forceinline__ void ba_role_obs(double* sh, int blk, const int* __restrict__ blk_start, const int* __restrict__ obs_pose,
+                                            const int* __restrict__ obs_point, const double* __restrict__ tab, const double* __restrict__ points,
                                             const double* __restrict__ uv, const BaK& k, double* __restrict__ r2, double* __restrict__ nrm,
-                                            double* __restrict__ Hpl) {
+                                            double* __restrict__ Hpl, double* __restrict__ Hll, double* __restrict__ bl) {
     const int tid = threadIdx.x;
-    const long o0 = (long)blk * 256;
+    const long o0 = blk_start[blk];
+    const int n = (int)(blk_start[blk + 1] - o0);
     const long o = o0 + tid;
-    if (o < M) {
+    const bool pts = FUSE && (Hll || bl);
+    double hpl[18];
+    int pid = -1;
+    if (tid < n) {
         const BaPose p = ba_load_pose<true>(tab, obs_pose[o]);
-        const double* Xp = points + (long)obs_point[o] * 3;
+        pid = obs_point[o];
+        const double* Xp = points + (long)pid * 3;
         const double X[3] = {Xp[0], Xp[1], Xp[2]};
         const double2 m = reinterpret_cast<const double2*>(uv)[o];
         double proj[2], Y[3], J0[3], J1[3], Jp[12], Jl[6];
@@ -156,20 +176,56 @@ __device__ __forceinline__ void ba_role_obs(double* sh, int blk, int M, const in
         const double r0 = proj[0] - m.x, r1 = proj[1] - m.y;
         if (r2) reinterpret_cast<double2*>(r2)[o] = double2{r0, r1};
         if (nrm) nrm[o] = sqrt(r0 * r0 + r1 * r1);
+        if (Hpl || pts) ba_jl(p, J0, J1, Jl);
         if (Hpl) {
-            ba_jl(p, J0, J1, Jl);
             ba_jp(p, Y, J0, J1, Jp);
-            double* h = sh + tid * BA_HPL_PITCH;
 #pragma unroll
             for (int a = 0; a < 6; a++)
 #pragma unroll
-                for (int b = 0; b < 3; b++) h[a * 3 + b] = Jp[a] * Jl[b] + Jp[6 + a] * Jl[3 + b];
+                for (int b = 0; b < 3; b++) hpl[a * 3 + b] = Jp[a] * Jl[b] + Jp[6 + a] * Jl[3 + b];
+        }
+        if (pts) {
+            double* t = sh + tid * BA_PT_PITCH;
+#pragma unroll
+            for (int a = 0; a < 3; a++) {
+#pragma unroll
+                for (int b = 0; b < 3; b++) t[a * 3 + b] = Jl[a] * Jl[b] + Jl[3 + a] * Jl[3 + b];
+                t[9 + a] = Jl[a] * r0 + Jl[3 + a] * r1;
+            }
+            reinterpret_cast<int*>(t + 12)[0] = pid;
         }
     }
+    if (pts) {
+        __syncthreads();
+        const bool head = tid < n && (tid == 0 || reinterpret_cast<const int*>(sh + (tid - 1) * BA_PT_PITCH + 12)[0] != pid);
+        if (head) {
+            double acc[12];
+#pragma unroll
+            for (int a = 0; a < 12; a++) acc[a] = 0;
+            for (int j = tid; j < n && reinterpret_cast<const int*>(sh + j * BA_PT_PITCH + 12)[0] == pid; j++) {
+                const double* t = sh + j * BA_PT_PITCH;
+#pragma unroll
+                for (int a = 0; a < 12; a++) acc[a] += t[a];
+            }
+            if (Hll)
+#pragma unroll
+                for (int a = 0; a < 9; a++) Hll[(long)pid * 9 + a] = acc[a];
+            if (bl)
+#pragma unroll
+                for (int a = 0; a < 3; a++) bl[(long)pid * 3 + a] = acc[9 + a];
+        }
+        if (!Hpl) return;
+        __syncthreads();     // the staging area is reused for Hpl
+    }
     if (!Hpl) return;
+    if (tid < n) {
+        double* h = sh + tid * BA_HPL_PITCH;
+#pragma unroll
+        for (int a = 0; a < 18; a++) h[a] = hpl[a];
+    }
     __syncthreads();
-    // the workgroup's 256 x 18 doubles are one contiguous run of Hpl: 16-byte stores, consecutive lanes consecutive addresses
-    const int n2 = (int)min(256L, (long)M - o0) * 9;               // double2 elements of the run
+    // the workgroup's n x 18 doubles are one contiguous run of Hpl: 16-byte stores, consecutive lanes consecutive addresses
+    const int n2 = n * 9;                                           // double2 elements of the run
     double2* dst = reinterpret_cast<double2*>(Hpl + o0 * 18);
     for (int e2 = tid; e2 < n2; e2 += 256) {
         const int l = e2 / 9, kk = 2 * (e2 - 9 * l);
@@ -207,21 +263,32 @@ __device__ __forceinline__ double ba_wave_sum(double v) {
 #define BA_POSE_UNROLL 2
 #endif
 #define BA_NSYM 27   // 21 unique entries of the symmetric 6x6 block + the 6 of bp
-__device__ __forceinline__ void ba_role_pose(double (*part)[BA_NSYM], int j, const int* __restrict__ pose_start, const int* __restrict__ pose_obs,
+// A workgroup serves BA_PPW poses, 4 / BA_PPW wavefronts each.  The role is latency bound (two dependent rounds of gathers per
+// trip), so what it costs the pass is the time its workgroups hold their slots: with one pose per workgroup the 1000 poses of
+// configs[4] took every slot of the chip for the first 17 us of the pass; four per workgroup (a wavefront each: 71 -> 60 us per pass; two: 63) leave two thirds of the slots to the
+// observation role from the start.
+#ifndef BA_PPW
+#define BA_PPW 4
+#endif
+__device__ __forceinline__ void ba_role_pose(double (*part)[BA_NSYM], int blk, int P, const int* __restrict__ pose_start, const int* __restrict__ pose_obs,
                                              const int* __restrict__ pose_pt, const double* __restrict__ tab, const double* __restrict__ points,
                                              const double* __restrict__ uv, const BaK& k, double* __restrict__ Hpp, double* __restrict__ bp) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int WPP = 4 / BA_PPW, LP = 64 * WPP;           // wavefronts and lanes per pose
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = wave / WPP, tid = (int)threadIdx.x - g * LP;   // the pose's place in the workgroup, the lane's place in the pose
+    const int jr = blk * BA_PPW + g;
+    const int j = min(jr, P - 1);                             // a group past the last pose runs pose P - 1 again and stores nothing
     const BaPose p = ba_load_pose<true>(tab, j);
     double acc[BA_NSYM];
 #pragma unroll
     for (int i = 0; i < BA_NSYM; i++) acc[i] = 0;
-    const int s = pose_start[j], e = pose_start[j + 1];
-    for (int q0 = s; q0 < e; q0 += BA_POSE_UNROLL * 256) {
+    const int s = pose_start[j], e = jr < P ? pose_start[j + 1] : s;
+    for (int q0 = s; q0 < e; q0 += BA_POSE_UNROLL * LP) {
         // BA_POSE_UNROLL observations per lane and trip: every index load, then every gather, is issued before the first use
         int oo[BA_POSE_UNROLL], ii[BA_POSE_UNROLL];
 #pragma unroll
         for (int u = 0; u < BA_POSE_UNROLL; u++) {
-            const int q = q0 + u * 256 + tid;
+            const int q = q0 + u * LP + tid;
             oo[u] = q < e ? pose_obs[q] : -1;
             ii[u] = q < e ? pose_pt[q] : 0;
         }
@@ -256,14 +323,18 @@ __device__ __forceinline__ void ba_role_pose(double (*part)[BA_NSYM], int j, con
         if (lane == 63) part[wave][i] = v;
     }
     __syncthreads();
-    if (tid < 42) {
+    if (tid < 42 && jr < P) {
         // entry (a, b) of the 6x6 block lives at its upper-triangle slot
         int slot;
         if (tid < 36) {
             const int a = tid / 6, b = tid - 6 * a, lo = min(a, b), hi = max(a, b);
             slot = lo * 6 - lo * (lo - 1) / 2 + (hi - lo);
         } else slot = 21 + (tid - 36);
-        const double v = (part[0][slot] + part[1][slot]) + (part[2][slot] + part[3][slot]);
+        const int w0 = g * WPP;
+        double v;
+        if (WPP == 4) v = (part[w0][slot] + part[w0 + 1][slot]) + (part[w0 + 2][slot] + part[w0 + 3][slot]);
+        else if (WPP == 2) v = part[w0][slot] + part[w0 + 1][slot];
+        else v = part[w0][slot];
         if (tid < 36) { if (Hpp) Hpp[(long)j * 36 + tid] = v; }
         else if (bp) bp[(long)j * 6 + (tid - 36)] = v;
     }
@@ -323,7 +394,8 @@ __device__ __forceinline__ void ba_role_point(int blk, int N, const int* __restr
 // against 76 us per pass).
 struct BaArgs {
     int P, N, M, n_pose_blk, n_point_blk;
-    const int *obs_pose, *obs_point, *pose_start, *pose_obs, *pose_pt, *point_start, *point_obs, *point_pose;
+    const int *obs_pose, *obs_point, *pose_start, *pose_obs, *pose_pt, *point_start, *point_obs, *point_pose, *blk_start;
+    int fuse_points;
     const double *tab, *points, *uv;
     double *r2, *nrm, *Hpp, *bp, *Hll, *bl, *Hpl;
     BaK k;
@@ -335,14 +407,15 @@ __global__ __launch_bounds__(256) void k_ba_pass(BaArgs a) {
     {
         const int n_obs_blk = (int)gridDim.x - a.n_pose_blk - a.n_point_blk;
         if (b < n_obs_blk) {
-            ba_role_obs(sh, b, a.M, a.obs_pose, a.obs_point, a.tab, a.points, a.uv, a.k, a.r2, a.nrm, a.Hpl);
+            if (a.fuse_points) ba_role_obs<true>(sh, b, a.blk_start, a.obs_pose, a.obs_point, a.tab, a.points, a.uv, a.k, a.r2, a.nrm, a.Hpl, a.Hll, a.bl);
+            else ba_role_obs<false>(sh, b, a.blk_start, a.obs_pose, a.obs_point, a.tab, a.points, a.uv, a.k, a.r2, a.nrm, a.Hpl, nullptr, nullptr);
             return;
         }
         b -= n_obs_blk;
     }
 #endif
     if (b < a.n_pose_blk) {
-        ba_role_pose(reinterpret_cast<double (*)[BA_NSYM]>(sh), b, a.pose_start, a.pose_obs, a.pose_pt, a.tab, a.points, a.uv, a.k, a.Hpp, a.bp);
+        ba_role_pose(reinterpret_cast<double (*)[BA_NSYM]>(sh), b, a.P, a.pose_start, a.pose_obs, a.pose_pt, a.tab, a.points, a.uv, a.k, a.Hpp, a.bp);
         return;
     }
     b -= a.n_pose_blk;
@@ -351,7 +424,8 @@ __global__ __launch_bounds__(256) void k_ba_pass(BaArgs a) {
         return;
     }
     b -= a.n_point_blk;
-    ba_role_obs(sh, b, a.M, a.obs_pose, a.obs_point, a.tab, a.points, a.uv, a.k, a.r2, a.nrm, a.Hpl);
+    if (a.fuse_points) ba_role_obs<true>(sh, b, a.blk_start, a.obs_pose, a.obs_point, a.tab, a.points, a.uv, a.k, a.r2, a.nrm, a.Hpl, a.Hll, a.bl);
+    else ba_role_obs<false>(sh, b, a.blk_start, a.obs_pose, a.obs_point, a.tab, a.points, a.uv, a.k, a.r2, a.nrm, a.Hpl, nullptr, nullptr);
 }
 
 // -------------------------------------------------------------------- C ABI
@@ -361,6 +435,7 @@ static void ba_free(vo_ba_plan* p) {
     if (p->stream) (void)hipStreamSynchronize(p->stream);
     (void)hipFree(p->d_obs_pose); (void)hipFree(p->d_obs_point); (void)hipFree(p->d_pose_start); (void)hipFree(p->d_pose_obs); (void)hipFree(p->d_pose_pt);
     (void)hipFree(p->d_point_start); (void)hipFree(p->d_point_obs); (void)hipFree(p->d_point_pose); (void)hipFree(p->d_tab); (void)hipFree(p->d_work);
+    (void)hipFree(p->d_blk_start); (void)hipFree(p->d_empty);
     if (p->stream) (void)hipStreamDestroy(p->stream);
     delete p;
 }
@@ -385,15 +460,46 @@ extern "C" int vo_ba_plan_create(int device, int P, int N, int M, const int32_t*
     }
     // the other index of every grouped observation, so that the kernels need no second dependent index load
     for (int q = 0; q < M; q++) { ppt[q] = obs_point[po[q]]; lps[q] = obs_pose[lo[q]]; }
+    // observation blocks of the main role.  Observations sorted by point (the usual layout): cut the blocks at point
+    // boundaries, at most 256 observations each, so that a point's observations never straddle two workgroups and its block
+    // sums can be made where the terms are computed.  Otherwise (or if one point has more than 256): plain blocks of 256 and
+    // the separate point role.
+    bool sorted = true;
+    for (int o = 1; o < M && sorted; o++) sorted = obs_point[o - 1] <= obs_point[o];
+    std::vector<int> bs{0}, empty;
+    bool fuse = sorted && M > 0;
+    if (fuse) {
+        int o = 0;
+        while (o < M && fuse) {
+            int e = o;           // extend by whole points while the block stays <= 256
+            while (e < M) {
+                int q = e;
+                while (q < M && obs_point[q] == obs_point[e]) q++;
+                if (q - o > 256) break;
+                e = q;
+            }
+            if (e == o) fuse = false;      // a single point with more than 256 observations
+            else { bs.push_back(e); o = e; }
+        }
+    }
+    if (!fuse) {
+        bs.assign(1, 0);
+        for (int o = 0; o < M; o += 256) bs.push_back(std::min(o + 256, M));
+    } else {
+        for (int i = 0; i < N; i++)
+            if (ls[i + 1] == ls[i]) empty.push_back(i);
+    }
     vo_ba_plan* p = new vo_ba_plan;
     p->device = device; p->P = P; p->N = N; p->M = M;
+    p->fuse_points = fuse; p->n_blk = (int)bs.size() - 1; p->n_empty = (int)empty.size();
     auto up = [&](int** d, const int* h, size_t n) -> bool {
         if (hipMalloc((void**)d, std::max<size_t>(n, 1) * sizeof(int)) != hipSuccess) return false;
         return n == 0 || hipMemcpy(*d, h, n * sizeof(int), hipMemcpyHostToDevice) == hipSuccess;
     };
     bool ok = up(&p->d_obs_pose, obs_pose, M) && up(&p->d_obs_point, obs_point, M) && up(&p->d_pose_start, ps.data(), P + 1) &&
               up(&p->d_pose_obs, po.data(), M) && up(&p->d_point_start, ls.data(), N + 1) && up(&p->d_point_obs, lo.data(), M) &&
-              up(&p->d_pose_pt, ppt.data(), M) && up(&p->d_point_pose, lps.data(), M);
+              up(&p->d_pose_pt, ppt.data(), M) && up(&p->d_point_pose, lps.data(), M) && up(&p->d_blk_start, bs.data(), bs.size()) &&
+              up(&p->d_empty, empty.data(), empty.size());
     ok = ok && hipMalloc((void**)&p->d_tab, (size_t)P * BA_TAB * sizeof(double)) == hipSuccess;
     ok = ok && hipStreamCreate(&p->stream) == hipSuccess;
     if (!ok) { ba_free(p); return VO_ERR_HIP; }
@@ -411,12 +517,15 @@ extern "C" int vo_ba_pass_device(vo_ba_plan* p, const double* poses, const doubl
     const BaK k{K[0], K[4], K[2], K[5]};
     // 16-byte accesses on uv / r / Hpl (double2); odd-aligned buffers are refused rather than read misaligned
     if ((((uintptr_t)uv | (uintptr_t)r2 | (uintptr_t)Hpl) & 15) != 0) return VO_ERR_INVALID;
-    hipLaunchKernelGGL(k_ba_rot, dim3((p->P + 255) / 256), dim3(256), 0, st, p->P, poses, p->d_tab);
+    const bool fuse = p->fuse_points && (Hll || bl);
+    const int n_empty = fuse ? p->n_empty : 0;
+    hipLaunchKernelGGL(k_ba_rot, dim3((std::max(p->P, n_empty) + 255) / 256), dim3(256), 0, st, p->P, poses, p->d_tab, n_empty, p->d_empty, Hll, bl);
     BaArgs a;
     a.P = p->P; a.N = p->N; a.M = p->M;
-    a.n_pose_blk = (Hpp || bp) ? p->P : 0;
-    a.n_point_blk = (Hll || bl) ? (p->N + 255) / 256 : 0;
-    const int n_obs_blk = (p->M > 0 && (r2 || nrm || Hpl)) ? (p->M + 255) / 256 : 0;
+    a.n_pose_blk = (Hpp || bp) ? (p->P + BA_PPW - 1) / BA_PPW : 0;
+    a.n_point_blk = ((Hll || bl) && !fuse) ? (p->N + 255) / 256 : 0;
+    const int n_obs_blk = (p->M > 0 && (r2 || nrm || Hpl || fuse)) ? p->n_blk : 0;
+    a.blk_start = p->d_blk_start; a.fuse_points = fuse ? 1 : 0;
     a.obs_pose = p->d_obs_pose; a.obs_point = p->d_obs_point; a.pose_start = p->d_pose_start; a.pose_obs = p->d_pose_obs; a.pose_pt = p->d_pose_pt;
     a.point_start = p->d_point_start; a.point_obs = p->d_point_obs; a.point_pose = p->d_point_pose;
     a.tab = p->d_tab; a.points = points; a.uv = uv;
