@@ -45,6 +45,11 @@ typedef struct {
     int32_t fma_atan;       /* A.1.6: 1 fastAtan2's polynomial contracts to fma (AVX2+FMA3 dispatch, default), 0 not */
     int32_t fma_blur;       /* A.1.7: 1 the float blur's a*b+c contract to fma (default), 0 not */
     int32_t trig_mode;      /* A.1.8: 0 (float)cos((double)angle) (default), 1 glibc cosf/sinf (the float overloads) */
+    /* Keypoints the workspace holds per frame; 0 = nfeatures + 1024.  retainBest keeps every keypoint that ties with the
+     * n-th best, so cv2 can return more than nfeatures; a frame beyond the capacity is reported VO_ERR_CAPACITY (never
+     * truncated), and a caller that wants cv2's behaviour for such frames creates a context with a larger capacity and
+     * retries, as the drop-in class does (visual_slam_amd/vo_utils.py).  At most 65535. */
+    int32_t keypoint_capacity;
 } vo_orb_params;
 
 /* cv::KeyPoint without class_id (always -1). */

@@ -203,3 +203,43 @@ def test_more_response_ties_than_the_keypoint_capacity_is_an_error(oracle):
         assert len(kg) == len(k2) and all(np.array_equal(kg[f], k2[f]) for f in k2.dtype.names) and np.array_equal(dg, d2)
     finally:
         ctx.close()
+
+
+def test_a_larger_keypoint_capacity_returns_what_cv2_would(oracle):
+    """The same frame of identical corners with vo_orb_params.keypoint_capacity raised: every tied keypoint comes back, bit
+    for bit the oracle's (= cv2's retainBest semantics); and the drop-in class does that retry by itself, so
+    get_matches behaves like libs/vo_utils.py:94-108 on such frames too."""
+    from visual_slam_amd import _lib
+    from visual_slam_amd.vo_utils import VisualOdometry
+    h, w = 376, 1241
+    img = np.full((h, w), 40, np.uint8)
+    img[4::8, 4::8] = 220
+    img[:, w // 2:] = np.where(img[:, w // 2:] == 220, 180, 40)      # two kinds of corners, so that descriptors can tell frames apart a little
+    ko, do = oracle.orb_detect_compute(img)
+    assert len(ko) > 3000 + 1024
+    ctx = _lib.Context(max_w=w, max_h=h, chunk_pairs=1, max_pairs=1, keypoint_capacity=12000)
+    try:
+        assert ctx.kp_cap == 12000
+        kg, dg = ctx.orb_detect_compute(img)
+        assert len(kg) == len(ko) and all(np.array_equal(kg[f], ko[f]) for f in ko.dtype.names) and np.array_equal(dg, do)
+        # the matcher and ratio test on that many descriptors (6 train segments)
+        i1, d1, i2, d2 = oracle.match_knn2(do, do)
+        g = ctx.match_knn2(dg, dg)
+        assert all(np.array_equal(a, b) for a, b in zip(g, (i1, d1, i2, d2)))
+    finally:
+        ctx.close()
+    vo = VisualOdometry.__new__(VisualOdometry)
+    vo.K, vo.D, vo.debug, vo._ctx, vo._ctx_shape = np.eye(3), np.zeros(5), False, None, None
+    shifted = np.roll(img, 8, axis=1)
+    try:
+        q1, q2 = vo.get_matches(1, "ORB", shifted, img)              # raises VO_ERR_CAPACITY internally, retries with a larger workspace
+    except ValueError:
+        q1 = q2 = np.zeros((0, 2), np.float32)                        # (no match may survive the ratio test on identical corners)
+    assert vo._ctx.kp_cap > 3000 + 1024 and q1.shape == q2.shape
+    k1, f1 = oracle.orb_detect_compute(img); k2, f2 = oracle.orb_detect_compute(shifted)
+    a1, b1, a2, b2 = oracle.match_knn2(f1, f2)
+    keep = oracle.ratio_filter(b1, b2, 0.45)
+    assert len(q1) == len(keep)
+    if len(keep):
+        assert np.array_equal(q1, np.stack([k1["x"][keep], k1["y"][keep]], 1)) and np.array_equal(q2, np.stack([k2["x"][a1[keep]], k2["y"][a1[keep]]], 1))
+    vo._ctx.close()

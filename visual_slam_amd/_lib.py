@@ -24,7 +24,7 @@ class OrbParams(C.Structure):
     _fields_ = [
         ("nfeatures", C.c_int32), ("scale_factor", C.c_float), ("nlevels", C.c_int32), ("edge_threshold", C.c_int32),
         ("patch_size", C.c_int32), ("fast_threshold", C.c_int32), ("blur_mode", C.c_int32), ("fma_atan", C.c_int32),
-        ("fma_blur", C.c_int32), ("trig_mode", C.c_int32),
+        ("fma_blur", C.c_int32), ("trig_mode", C.c_int32), ("keypoint_capacity", C.c_int32),
     ]
 
 
@@ -124,7 +124,8 @@ class Context:
                 self.lib.vo_ctx_destroy(h)
             self.h = None
             raise VoError(rc, msg)
-        self.kp_cap = self.params.nfeatures + 1024
+        kc = self.params.keypoint_capacity
+        self.kp_cap = max(kc, self.params.nfeatures) if kc > 0 else self.params.nfeatures + 1024     # mirrors lane_init (vo_api.hip)
         self.device = device
         self.chunk_pairs, self.max_pairs = chunk_pairs, max(max_pairs, chunk_pairs)
         self._inflight = []

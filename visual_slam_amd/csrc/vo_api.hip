@@ -104,6 +104,7 @@ void vo_default_orb_params(vo_orb_params* p) {
     p->fma_atan = 1;
     p->fma_blur = 1;
     p->trig_mode = 0;
+    p->keypoint_capacity = 0;
 }
 
 // Streams, events and the per-chunk workspace of ONE lane (the context itself is lane 0; extra lanes are shallow clones
@@ -119,7 +120,7 @@ static int lane_init(vo_ctx* c, bool with_aux) {
     HIP_TRY(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
     HIP_TRY(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
     for (int i = 0; i < 2; i++) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_lane[i], hipEventDisableTiming));
-    c->kp_cap = p.nfeatures + 1024;
+    c->kp_cap = p.keypoint_capacity > 0 ? std::max(p.keypoint_capacity, p.nfeatures) : p.nfeatures + 1024;
     const long F = c->max_frames, kc = c->kp_cap, CP = c->chunk_pairs;
     // upper bounds from the max image size (all quantities are monotone in w, h)
     const long W = c->max_w, H = c->max_h;
@@ -261,7 +262,8 @@ int vo_ctx_create(int device, int max_w, int max_h, int chunk_pairs, int max_pai
     if (max_w < 64 || max_h < 64 || max_w > 4095 || max_h > 4095 || chunk_pairs < 1 || max_pairs < 1 || chunk_pairs > 16384)
         return vo_fail(c, VO_ERR_INVALID, "vo_ctx_create: size arguments out of range");
     if (p.nlevels < 1 || p.nlevels > VO_MAX_LEVELS || p.patch_size != 31 || p.edge_threshold != 31 || p.nfeatures < 1 || p.nfeatures > 60000 ||
-        p.fast_threshold < 1 || p.fast_threshold > 254 || (p.blur_mode != 0 && p.blur_mode != 1) || (p.trig_mode != 0 && p.trig_mode != 1))
+        p.fast_threshold < 1 || p.fast_threshold > 254 || (p.blur_mode != 0 && p.blur_mode != 1) || (p.trig_mode != 0 && p.trig_mode != 1) ||
+        p.keypoint_capacity < 0 || p.keypoint_capacity > 65535)
         return vo_fail(c, VO_ERR_INVALID, "vo_ctx_create: unsupported ORB parameters");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= device || device < 0)

@@ -40,11 +40,11 @@ class VisualOdometry():
         self._ctx = None
         self._ctx_shape = None
 
-    def _context(self, h, w):
-        if self._ctx is None or self._ctx_shape != (h, w):
+    def _context(self, h, w, keypoint_capacity=0):
+        if self._ctx is None or self._ctx_shape != (h, w) or keypoint_capacity > self._ctx.kp_cap:
             if self._ctx is not None:
                 self._ctx.close()
-            self._ctx = _lib.Context(max_w=w, max_h=h, chunk_pairs=1, max_pairs=1, nfeatures=3000)
+            self._ctx = _lib.Context(max_w=w, max_h=h, chunk_pairs=1, max_pairs=1, nfeatures=3000, keypoint_capacity=keypoint_capacity)
             self._ctx_shape = (h, w)
         return self._ctx
 
@@ -103,13 +103,20 @@ class VisualOdometry():
         ctx = self._context(*img1.shape)
         # detectAndCompute x2 + knnMatch + ratio loop + the two list comprehensions (:94-108) are ONE library call:
         # both frames are extracted in one launch wave and matched on the device, only q1 / q2 come back
-        try:
-            q1, q2 = ctx.get_matches(img1, img2, ratio)
-        except _lib.VoError as e:
-            if e.code == _lib.VO_ERR_TOO_FEW:
-                # knnMatch returns fewer than 2 neighbours -> `for m,n in matches` raises in the reference
-                raise ValueError("not enough values to unpack (expected 2 neighbours per match)") from e
-            raise
+        while True:
+            try:
+                q1, q2 = ctx.get_matches(img1, img2, ratio)
+                break
+            except _lib.VoError as e:
+                if e.code == _lib.VO_ERR_TOO_FEW:
+                    # knnMatch returns fewer than 2 neighbours -> `for m,n in matches` raises in the reference
+                    raise ValueError("not enough values to unpack (expected 2 neighbours per match)") from e
+                if e.code == _lib.VO_ERR_CAPACITY and ctx.kp_cap < 65535:
+                    # retainBest keeps every tie at the cut, so cv2 returns more than nfeatures keypoints for such a frame
+                    # (libs/vo_utils.py:94-95 takes whatever comes): same here, with a workspace that holds them
+                    ctx = self._context(*img1.shape, keypoint_capacity=min(65535, 2 * ctx.kp_cap))
+                    continue
+                raise
         if len(q1) == 0:
             return np.float32([]), np.float32([])     # np.float32([]) has shape (0,), as in the reference
         return q1, q2
