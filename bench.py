@@ -36,8 +36,9 @@ MFMA_I8_PEAK_TOPS = 256 * 4 * 2048 * 2.4e9 / 1e12
 # VALU issue (MI355X_MICROARCH.md: a wave64 VALU instruction issues over 2 cycles, 32 lanes per cycle and SIMD):
 # 256 CU x 4 SIMD x 2.4 GHz / 2 = 1.229 T wave64-instructions/s = 78.6 T lane-ops/s at full rate
 VALU_PEAK_WAVE_INSTS = 256 * 4 * 2.4e9 / 2
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r2_pmc_hbm_traffic.json")
-VALU_FILE = os.path.join(ROOT, "profiles", "r2_pmc_valu.json")
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r3_pmc_hbm_traffic.json")
+VALU_FILE = os.path.join(ROOT, "profiles", "r3_pmc_valu.json")
+BA_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r3_ba_pmc_hbm_traffic.json")
 KITTI_DIR = os.path.join(ROOT, "tests", "golden", "kitti02")
 
 
@@ -102,7 +103,7 @@ def valu_roofline(kernel, frames_per_launch, avg_launch_s, P, w, h):
     return {"wave_insts_per_launch": int(insts), "insts_per_px": round(insts * 64 / (P * frames_per_launch), 2),
             "achieved": round(achieved / 1e9, 2), "peak": round(VALU_PEAK_WAVE_INSTS / 1e9, 1), "unit": "G wave64-instructions/s",
             "frac": round(achieved / VALU_PEAK_WAVE_INSTS, 4), "issue_frac_at_measured_clock": t["kernels"][kernel].get("valu_issue_frac"),
-            "note": "peak = every SIMD issuing one full-rate wave64 VALU instruction per 2 cycles (nominal 2.4 GHz); issue_frac_at_measured_clock = SQ_INSTS_VALU / (16 x SQ_BUSY_CYCLES) from the same PMC pass. 84 % of the hot stage's instructions (71 % of the kernel's, counted in the ISA) are half-rate (v_min/v_max SDWA, v_min3/v_max3, v_cmp, v_mbcnt), two issue slots each: 0.45 of the full-rate peak is about 0.8 of what this mix can issue (DESIGN.md 3.3)"}
+            "note": "peak = every SIMD issuing one full-rate wave64 VALU instruction per 2 cycles (nominal 2.4 GHz); issue_frac_at_measured_clock = SQ_INSTS_VALU / (16 x SQ_BUSY_CYCLES) from the same PMC pass. Most of the kernel's instructions are half-rate (v_lerp_u8, v_perm, v_min3/v_max3, v_cmp, v_mbcnt, VOP3 forms: 4.4-4.9 cycles against 2.7 for a full-rate one, tools/ubench3.hip), and its LDS pipe is as busy as its VALU (profiles/r3_c_pmc_lds.csv): DESIGN.md 3.3"}
 
 
 def cpu_model():
@@ -742,7 +743,15 @@ def main():
                 side.synchronize()
                 kb["whole_pass"] = e0.elapsed_time(e1) / 10
             a_ba = ba_bytes / (kb["whole_pass"] * 1e-3) / 1e9
-            ba_out["roofline"] = {"bound": "hbm", "achieved": round(a_ba, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(a_ba / HBM_PEAK_GBS, 4),
+            ba_traffic = None
+            try:        # the committed FETCH_SIZE / WRITE_SIZE passes describe the whole configs[4] problem on one rank
+                with open(BA_TRAFFIC_FILE) as f:
+                    bt = json.load(f)
+                if world == 1 and bt["meta"]["observations"] == M:
+                    ba_traffic = int(sum(2.0 * k_["FETCH_SIZE_KB_avg_per_launch"] + k_["WRITE_SIZE_KB_avg_per_launch"] for k_ in bt["kernels"].values()) * 1024)
+            except Exception:
+                pass
+            ba_out["roofline"] = {"bound": "hbm", "achieved": round(a_ba, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(a_ba / HBM_PEAK_GBS, 4), "traffic": ba_traffic,
                                   "bytes_per_pass": int(ba_bytes), "device_ms_per_pass": round(kb["whole_pass"], 5),
                                   "note": "HIP events on the launch stream, 10 passes back to back (k_ba_rot + k_ba_pass per pass; kernel durations: profiles/r3_*_ba_kernel_stats.csv); ms_per_pass above is host wall clock per synchronous call (+ the all-reduce at N > 1)"}
         plan.close()
