@@ -107,7 +107,7 @@ class BAPlan:
             raise _lib.VoError(rc, "vo_ba_pass_device failed")
 
 
-def allreduce_pose_blocks(Hpp, bp):
+def allreduce_pose_blocks(Hpp, bp, force=False):
     """Sum the pose blocks of every rank (observations sharded by point): ONE all_reduce of the
     packed [P,42] float64 buffer (36 J^T J + 6 J^T r per pose; 336 KB at P = 1000) -- the only
     collective of the BA pass.  Tensors (any device) or numpy arrays; returns the same kind.
@@ -115,7 +115,7 @@ def allreduce_pose_blocks(Hpp, bp):
     import torch
     import torch.distributed as dist
 
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not force):
         return Hpp, bp
     is_np = isinstance(Hpp, np.ndarray)
     tH = torch.from_numpy(np.ascontiguousarray(Hpp)) if is_np else Hpp

@@ -30,6 +30,9 @@
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 
+#ifndef VO_MATCH_NQ
+#define VO_MATCH_NQ 3                  // query tiles (of 32) a wavefront keeps in registers
+#endif
 #define MATCH_SEG_TRAINS 2016         // trains per segment: 63 blocks of 32 (12-bit block-relative index)
 #define MM_QPB (4 * MM_NQ * 32)      // queries per 256-thread block (MM_NQ 32-query tiles per wavefront)
 #define MM_REGION 528                // LDS bytes per (k-step, half) region: 32 trains x 16 B + 16 B pad
@@ -256,7 +259,7 @@ int vo_match_segments(int kp_cap) { return std::max(4, (kp_cap + MATCH_SEG_TRAIN
 int vo_launch_match_impl(vo_ctx* c, int P, int nA, double ratio, int pair0, int4* raw_out, hipStream_t st) {
     const int kp_cap = c->kp_cap;
     const int nseg = vo_match_segments(kp_cap);
-    KT(c, st, VO_K_MATCH, hipLaunchKernelGGL(k_match<3>, dim3((kp_cap + 383) / 384, nseg, P), dim3(256), 0, st, (const uint8_t*)c->d_desc.p,
+    KT(c, st, VO_K_MATCH, hipLaunchKernelGGL(k_match<VO_MATCH_NQ>, dim3((kp_cap + 128 * VO_MATCH_NQ - 1) / (128 * VO_MATCH_NQ), nseg, P), dim3(256), 0, st, (const uint8_t*)c->d_desc.p,
                                              (const int*)c->d_nkp.p, kp_cap, nA, nseg, (uint2*)c->d_match.p));
     KT(c, st, VO_K_RATIO, hipLaunchKernelGGL(k_ratio, dim3(P), dim3(1024), 0, st, (const uint2*)c->d_match.p, nseg, (const int*)c->d_nkp.p, kp_cap, nA,
                        (const vo_keypoint*)c->d_kp.p, ratio, pair0, (int4*)c->mq(), (float2*)c->q1(), (float2*)c->q2(),
@@ -326,7 +329,7 @@ extern "C" int vo_match_knn2_ratio_noalloc(vo_ctx* c, const uint8_t* q_dev, int 
     hipLaunchKernelGGL(k_noalloc_setup, dim3(1), dim3(64), 0, st, small, nq, nt);
     if (nq) HIP_TRY(c, hipMemcpyAsync(desc, q_dev, (size_t)nq * 32, hipMemcpyDeviceToDevice, st));
     HIP_TRY(c, hipMemcpyAsync(desc + (long)NA_CAP * 32, t_dev, (size_t)nt * 32, hipMemcpyDeviceToDevice, st));
-    hipLaunchKernelGGL(k_match<3>, dim3((NA_CAP + 383) / 384, NA_NSEG, 1), dim3(256), 0, st, (const uint8_t*)desc, (const int*)small, NA_CAP, 1, NA_NSEG, seg);
+    hipLaunchKernelGGL(k_match<VO_MATCH_NQ>, dim3((NA_CAP + 128 * VO_MATCH_NQ - 1) / (128 * VO_MATCH_NQ), NA_NSEG, 1), dim3(256), 0, st, (const uint8_t*)desc, (const int*)small, NA_CAP, 1, NA_NSEG, seg);
     hipLaunchKernelGGL(k_ratio, dim3(1), dim3(1024), 0, st, (const uint2*)seg, NA_NSEG, (const int*)small, NA_CAP, 1, (const vo_keypoint*)nullptr, ratio, 0, mq,
                        (float2*)nullptr, (float2*)nullptr, small + 4, small + 5, (int2*)(small + 6), (const int*)(small + 2), (int4*)nullptr);
     hipLaunchKernelGGL(k_noalloc_out, dim3((NA_CAP + 255) / 256), dim3(256), 0, st, (const int4*)mq, (const int*)small, cap, (int4*)matches_dev, (int*)n_dev);

@@ -12,13 +12,14 @@ def shard_range(total, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def gather_pair_results(local, total, device=None):
+def gather_pair_results(local, total, device=None, force=False):
     """all_gather of the per-pair result records (numpy structured array) of every rank, in pair
-    order.  Works on any initialised backend; without an initialised group returns `local`."""
+    order.  Works on any initialised backend; without an initialised group returns `local`.
+    `force`: go through the collective even in a group of one rank (a test of the RCCL path on a one-GPU box)."""
     import torch
     import torch.distributed as dist
 
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not force):
         return local
     world = dist.get_world_size()
     dev = device if device is not None else (torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else "cpu")
@@ -36,12 +37,12 @@ def gather_pair_results(local, total, device=None):
     return np.concatenate(out)
 
 
-def max_over_ranks(value, device=None):
+def max_over_ranks(value, device=None, force=False):
     """MAX all-reduce of a python float (the bench's step time)."""
     import torch
     import torch.distributed as dist
 
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not force):
         return float(value)
     dev = device if device is not None else (torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else "cpu")
     t = torch.tensor([value], dtype=torch.float64, device=dev)
