@@ -30,8 +30,11 @@
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 
+// query tiles (of 32) a wavefront keeps in registers.  3: 248 VGPRs, two wavefronts per SIMD.  2 (200 VGPRs, still two per
+// SIMD; every 32-train block's expansion, LDS round trip and barrier then serve 16 instead of 24 MFMAs) measured 86 against
+// 69 us per launch (round 3).
 #ifndef VO_MATCH_NQ
-#define VO_MATCH_NQ 3                  // query tiles (of 32) a wavefront keeps in registers
+#define VO_MATCH_NQ 3
 #endif
 #define MATCH_SEG_TRAINS 2016         // trains per segment: 63 blocks of 32 (12-bit block-relative index)
 #define MM_QPB (4 * MM_NQ * 32)      // queries per 256-thread block (MM_NQ 32-query tiles per wavefront)
