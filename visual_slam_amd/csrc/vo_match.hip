@@ -36,6 +36,13 @@ typedef int v16i __attribute__((ext_vector_type(16)));
 #ifndef VO_MATCH_NQ
 #define VO_MATCH_NQ 3
 #endif
+// a launch splits the train set into as few segments as still give this many workgroups (two per CU): every segment repeats the
+// query tiles' load + expansion and a workgroup's loop is only as long as its segment.  32 pairs x 3000: 2 segments of 47 blocks
+// instead of 4 of 24: k_match alone 70 -> 81 us (one round of equal workgroups that run in lock step), but the pipeline +1.4 %
+// (57.1 -> 57.9 k pairs/s, three A/B runs each on one box): half the prologues, half the k_ratio merge reads.
+#ifndef VO_MATCH_FILL_WGS
+#define VO_MATCH_FILL_WGS 512
+#endif
 #define MATCH_SEG_TRAINS 2016         // trains per segment: 63 blocks of 32 (12-bit block-relative index)
 #define MM_QPB (4 * MM_NQ * 32)      // queries per 256-thread block (MM_NQ 32-query tiles per wavefront)
 #define MM_REGION 528                // LDS bytes per (k-step, half) region: 32 trains x 16 B + 16 B pad
@@ -261,8 +268,12 @@ int vo_match_segments(int kp_cap) { return std::max(4, (kp_cap + MATCH_SEG_TRAIN
 // pairs of the chunk: query frame p, train frame nA + p (descriptors of the last detect)
 int vo_launch_match_impl(vo_ctx* c, int P, int nA, double ratio, int pair0, int4* raw_out, hipStream_t st) {
     const int kp_cap = c->kp_cap;
-    const int nseg = vo_match_segments(kp_cap);
-    KT(c, st, VO_K_MATCH, hipLaunchKernelGGL(k_match<VO_MATCH_NQ>, dim3((kp_cap + 128 * VO_MATCH_NQ - 1) / (128 * VO_MATCH_NQ), nseg, P), dim3(256), 0, st, (const uint8_t*)c->d_desc.p,
+    // d_match holds vo_match_segments(kp_cap) segments per pair; a launch uses as few of them as still give VO_MATCH_FILL_WGS
+    // workgroups (every segment repeats the query tiles' load + expansion, and a workgroup's loop is only as long as its segment)
+    const int gx = (kp_cap + 128 * VO_MATCH_NQ - 1) / (128 * VO_MATCH_NQ);
+    const int nseg_min = (kp_cap + MATCH_SEG_TRAINS - 1) / MATCH_SEG_TRAINS;
+    const int nseg = std::min(vo_match_segments(kp_cap), std::max(nseg_min, (VO_MATCH_FILL_WGS + gx * P - 1) / (gx * P)));
+    KT(c, st, VO_K_MATCH, hipLaunchKernelGGL(k_match<VO_MATCH_NQ>, dim3(gx, nseg, P), dim3(256), 0, st, (const uint8_t*)c->d_desc.p,
                                              (const int*)c->d_nkp.p, kp_cap, nA, nseg, (uint2*)c->d_match.p));
     KT(c, st, VO_K_RATIO, hipLaunchKernelGGL(k_ratio, dim3(P), dim3(1024), 0, st, (const uint2*)c->d_match.p, nseg, (const int*)c->d_nkp.p, kp_cap, nA,
                        (const vo_keypoint*)c->d_kp.p, ratio, pair0, (int4*)c->mq(), (float2*)c->q1(), (float2*)c->q2(),
