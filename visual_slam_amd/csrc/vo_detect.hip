@@ -195,8 +195,12 @@ __global__ __launch_bounds__(256) void k_pyramid(const Geom* __restrict__ g, Fra
     const uint4 cy4 = *reinterpret_cast<const uint4*>(yt + (uint32_t)y0);
     const uint32_t cx[4] = {cx4.x, cx4.y, cx4.z, cx4.w};
     const int nvalid = min(4, L.w - x4);
-    const int o0 = (int)(cx[0] & 0xFFFF);
+    // first source column of the lane's 8-byte window.  At the right edge the window is pulled back inside the row: the last
+    // lanes of a row then stay on the fast path (a wavefront whose edge lane took the general path below executed BOTH, and
+    // that was a third of all wavefronts).  A pixel at relative position 7 has no right neighbour in the window; that only
+    // happens for source column sw-1, whose coefficient pair is (256, 0), so whatever the selector picks is multiplied by 0.
     const int olast = (int)(cx[3] & 0xFFFF);
+    const int o0 = min((int)(cx[0] & 0xFFFF), max(sw - 8, 0));
     uint8_t* const lbase = pyr + (long)f * g->pyr_frame + L.pyr_ofs;             // uniform
     const uint32_t dofs = (uint32_t)y0 * (uint32_t)L.pitch + (uint32_t)x4;
     static_assert(PYR_ROWS == 4, "one uint4 of row coefficients per lane");
@@ -379,10 +383,13 @@ __global__ __launch_bounds__(256) void k_fast_tiles(const Geom* __restrict__ g, 
                     uint32_t v;
                     if (whole) {
                         __builtin_memcpy(&v, rp + x, 4);
+                    } else if (x < Lw) {
+                        // the dword crosses the level's right edge: the row's last four pixels, shifted so that column x is byte 0.
+                        // Columns >= Lw come out 0; no position FAST evaluates (3 px inside the level) reads them.
+                        __builtin_memcpy(&v, rp + (Lw - 4), 4);
+                        v >>= 8 * (x - (Lw - 4));
                     } else {
                         v = 0;
-#pragma unroll
-                        for (int j = 0; j < 4; j++) v |= (uint32_t)rp[min(x + j, Lw - 1)] << (8 * j);
                     }
                     *reinterpret_cast<uint32_t*>(&px[r * PXP + 4 * k]) = v;
                 }
@@ -397,14 +404,19 @@ __global__ __launch_bounds__(256) void k_fast_tiles(const Geom* __restrict__ g, 
     //   min_k max(p_k, p_k+8) > v+t   (brighter)   or   max_k min(p_k, p_k+8) < v-t   (darker)  is necessary.
     // Survivors go to a brighter and/or a darker queue so that stage 2 runs dense, polarity-uniform
     // wavefronts; one LDS atomic per wavefront and iteration reserves the queue space.
-    const int cmax = min(VO_TILE_W + 2, Lw - 3 - (x0 - 1));   // FAST is defined 3 px inside the level
-    const int rmax = Lh - 3 - (y0 - 1);
+    // Score positions that can matter: an output must lie VO_EDGE inside the level (stage 3), and its 3 x 3 neighbourhood
+    // reaches one position further -- image x <= Lw - VO_EDGE, y <= Lh - VO_EDGE.  (FAST itself is defined up to 3 px from
+    // the border, but scores out there only feed outputs that the border filter drops.)
+    static_assert(VO_EDGE >= 4, "the needed positions lie inside FAST's own 3-px border");
+    const int cmax = min(VO_TILE_W + 2, Lw - VO_EDGE - x0 + 2);
+    const int rmax = Lh - VO_EDGE - y0 + 2;
 #ifndef VO_FAST_MINMAX_PRETEST
     const uint32_t T2 = (uint32_t)thr | ((uint32_t)thr << 16);
     // bit 7 of byte i set iff position k4 + i of this lane's run is a position of the level (the row test is made per iteration)
     const int nval = min(max(cmax - (int)((tid & 15) * 4), 0), 4);
     const uint32_t colmask = nval >= 4 ? 0x80808080u : (0x80808080u & ((1u << (8 * nval)) - 1u));
 #endif
+    const int wave_s = __builtin_amdgcn_readfirstlane(wave);
 #pragma unroll
     for (int it = 0; it < 2; it++) {
         // 16 runs of 4 positions per row, 16 rows per iteration.  The two rows that share a half-wavefront (32 lanes = one LDS
@@ -412,6 +424,10 @@ __global__ __launch_bounds__(256) void k_fast_tiles(const Geom* __restrict__ g, 
         // (4 x 20 = 16 mod 32), where adjacent rows (offset 20) collide in 12 of 16 banks.
         const int slot = tid >> 4;               // 0..15
         const int r = 16 * it + ((slot >> 3) << 3) + ((slot & 1) << 2) + ((slot >> 1) & 3), k4 = (tid & 15) * 4;
+        *reinterpret_cast<uint32_t*>(&sc[r * SCP + k4]) = 0;
+        // rows at or below the level's last FAST row (bottom tiles: 9 % of all tile rows lie outside their level) have no
+        // position to test; the smallest row of this wavefront's four is 16 it + {0, 2, 8, 10}[wave] (scalar branch)
+        if (16 * it + ((wave_s >> 1) << 3) + ((wave_s & 1) << 1) >= rmax) continue;
         const uint32_t* rowC = reinterpret_cast<const uint32_t*>(&px[(r + 3) * PXP + k4]);
         const uint32_t* rowP2 = reinterpret_cast<const uint32_t*>(&px[(r + 5) * PXP + k4]);
         const uint32_t* rowM2 = reinterpret_cast<const uint32_t*>(&px[(r + 1) * PXP + k4]);
@@ -420,7 +436,6 @@ __global__ __launch_bounds__(256) void k_fast_tiles(const Geom* __restrict__ g, 
         const uint32_t C0 = rowC[0], C1 = rowC[1], C2 = rowC[2], C3 = rowC[3];
         const uint32_t P21 = rowP2[1], P22 = rowP2[2], M21 = rowM2[1], M22 = rowM2[2];
         const uint32_t P31 = rowP3[1], P32 = rowP3[2], M31 = rowM3[1], M32 = rowM3[2];
-        *reinterpret_cast<uint32_t*>(&sc[r * SCP + k4]) = 0;
 #ifdef VO_FAST_MINMAX_PRETEST
         // position i: centre = LDS col k4+6+i;  mm = min over pairs of max, xm = max over pairs of min
 #define PRETEST(i, v, a0, a8, a2, a10, a4, a12, a6, a14)                                                             \
@@ -1190,10 +1205,19 @@ __global__ __launch_bounds__(256) void k_blur(const Geom* __restrict__ g, FrameS
                 uint32_t v;
                 if (whole) {
                     __builtin_memcpy(&v, img + (ro + (uint32_t)x), 4);
+                } else if (x < 0) {
+                    // x = -4 (tile column 0): columns -4 .. -1 reflect to 4, 3, 2, 1 = the dword at column 1, bytes reversed
+                    uint32_t d;
+                    __builtin_memcpy(&d, img + (ro + 1u), 4);
+                    v = __builtin_amdgcn_perm(0u, d, 0x00010203u);
                 } else {
-                    v = 0;
-#pragma unroll
-                    for (int b = 0; b < 4; b++) v |= (uint32_t)img[ro + (uint32_t)reflect101c(x + b, L.w)] << (8 * b);
+                    // at or beyond the right edge: with [a b c d] the row's last four pixels the reflected row continues
+                    // d | c b a ?, and the outputs that are stored (x < L.w) reach no further than column L.w + 2 (= a)
+                    uint32_t d;
+                    __builtin_memcpy(&d, img + (ro + (uint32_t)(L.w - 4)), 4);
+                    const unsigned long long e = (unsigned long long)d | ((unsigned long long)__builtin_amdgcn_perm(0u, d, 0x0C000102u) << 32);
+                    const int sft = x - (L.w - 4);
+                    v = sft < 8 ? (uint32_t)(e >> (8 * sft)) : 0u;
                 }
                 *reinterpret_cast<uint32_t*>(&sp[r * BL_SP + 4 * k]) = v;
             }
@@ -1287,7 +1311,8 @@ __global__ __launch_bounds__(256) void k_blur(const Geom* __restrict__ g, FrameS
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     // SymmColumnFilter: s = k0*row[0] + delta; s += k[i]*(row[i] + row[-i])
-                    float acc = kw[0] * comp4(q[o + 3], j) + 0.f;
+                    // (delta = 0 is not added: the product of a positive weight and a row sum >= +0 is never -0, so `+ 0.f` is the identity)
+                    float acc = kw[0] * comp4(q[o + 3], j);
                     const float t1 = comp4(q[o + 4], j) + comp4(q[o + 2], j);
                     const float t2 = comp4(q[o + 5], j) + comp4(q[o + 1], j);
                     const float t3 = comp4(q[o + 6], j) + comp4(q[o], j);
