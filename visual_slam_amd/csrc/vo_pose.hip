@@ -262,6 +262,9 @@ __device__ __forceinline__ Cx cdiv(Cx a, Cx b) {
 #define DK_SWEEPS 300  // cv::solvePoly's maxIters at the reference's call (timing experiments lower it)
 #endif
 #ifndef VO_WIDE_SOLVE_MAX_HYP
+#ifndef VO_WIDE_SOLVE_ASYNC_MAX_HYP
+#define VO_WIDE_SOLVE_ASYNC_MAX_HYP 512
+#endif
 #define VO_WIDE_SOLVE_MAX_HYP 2048   // hypotheses per round up to which the 16-lanes-per-hypothesis solver runs (measured crossover: 1.73 against 2.05 ms at 2048, 2.65 against 2.07 ms at 4096)
 #endif
 // -DFP_CLOCKS (experiment builds, tools/exp_solver_clocks.py): the solver stamps the cycle counter at its phase boundaries into
@@ -1263,7 +1266,7 @@ int vo_launch_ransac(vo_ctx* c, int P, const double K[9], double prob, double th
         // few hypotheses in the round (single pairs, small batches): a DPP row per hypothesis, one wavefront per SIMD at most
         // (the asynchronous entry points overlap the pose stage with the next submission's detect kernels, where the 16-lane form's
         // ten-fold VALU work would cost throughput: they only take it for rounds of <= 512 hypotheses)
-        if ((long)P * nh <= (host_free ? 512 : VO_WIDE_SOLVE_MAX_HYP))
+        if ((long)P * nh <= (host_free ? VO_WIDE_SOLVE_ASYNC_MAX_HYP : VO_WIDE_SOLVE_MAX_HYP))
             hipLaunchKernelGGL(k_ransac_solve_wide, dim3((P * nh * 16 + DK_T - 1) / DK_T), dim3(DK_T), 0, st, pw, nmatch, P, nh, kp_cap, q1, q2, nk, samples, models, nmodels);
         else
             hipLaunchKernelGGL(k_ransac_solve, dim3((P * nh + DK_T - 1) / DK_T), dim3(DK_T), 0, st, pw, nmatch, P, nh, kp_cap, q1, q2, nk, samples, models, nmodels);
