@@ -67,15 +67,16 @@ __device__ __forceinline__ void key_update(uint32_t key, uint32_t& k1, uint32_t&
 
 template <int MM_NQ>
 __global__ __launch_bounds__(256) void k_match(const uint8_t* __restrict__ desc, const int* __restrict__ nkp, int kp_cap, int nA,
-                                               int nseg, uint2* __restrict__ seg_best) {
+                                               int nseg, uint2* __restrict__ seg_best, int xb0) {
     __shared__ __attribute__((aligned(16))) uint8_t abuf[2 * MM_BUF];
     const int p = blockIdx.z, seg = blockIdx.y;
     const int qf = p, tf = nA + p;
     const int nq = nkp[qf], nt = nkp[tf];
-    if ((int)blockIdx.x * MM_QPB >= nq) return;
+    const int xb = (int)blockIdx.x + xb0;   // query block (a launch covers the blocks xb0 .. xb0 + gridDim.x - 1)
+    if (xb * MM_QPB >= nq) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 31, h = lane >> 5;
-    const int q0 = blockIdx.x * MM_QPB + wave * (MM_NQ * 32);
+    const int q0 = xb * MM_QPB + wave * (MM_NQ * 32);
     // query tiles: lane (n, h) holds half h of query q0 + 32u + n, recoded to +1 / -1; k-step s = bits [16s, 16s+16) of the half
     v4i B[MM_NQ][8];
     int pc[MM_NQ];
@@ -270,11 +271,21 @@ int vo_launch_match_impl(vo_ctx* c, int P, int nA, double ratio, int pair0, int4
     const int kp_cap = c->kp_cap;
     // d_match holds vo_match_segments(kp_cap) segments per pair; a launch uses as few of them as still give VO_MATCH_FILL_WGS
     // workgroups (every segment repeats the query tiles' load + expansion, and a workgroup's loop is only as long as its segment)
-    const int gx = (kp_cap + 128 * VO_MATCH_NQ - 1) / (128 * VO_MATCH_NQ);
+    // Query blocks: a frame has nfeatures keypoints unless responses tie at the cut (then up to kp_cap).  The main launch covers
+    // the blocks up to nfeatures -- every workgroup of it has work, and with two resident workgroups per CU (248 VGPRs) 32 pairs x
+    // 8 blocks x 2 segments are exactly one round; launched over kp_cap, a quarter of the grid exited at once and the dispatcher
+    // spread the working ones unevenly (wavefront slots 65 % occupied over the kernel's time).  The blocks beyond nfeatures get
+    // a launch of their own, whose workgroups exit at their first test unless a frame did tie.
+    const int qpb = 128 * VO_MATCH_NQ;
+    const int gx_all = (kp_cap + qpb - 1) / qpb;
+    const int gx = std::min(gx_all, (std::min(c->params.nfeatures, kp_cap) + qpb - 1) / qpb);
     const int nseg_min = (kp_cap + MATCH_SEG_TRAINS - 1) / MATCH_SEG_TRAINS;
     const int nseg = std::min(vo_match_segments(kp_cap), std::max(nseg_min, (VO_MATCH_FILL_WGS + gx * P - 1) / (gx * P)));
     KT(c, st, VO_K_MATCH, hipLaunchKernelGGL(k_match<VO_MATCH_NQ>, dim3(gx, nseg, P), dim3(256), 0, st, (const uint8_t*)c->d_desc.p,
-                                             (const int*)c->d_nkp.p, kp_cap, nA, nseg, (uint2*)c->d_match.p));
+                                             (const int*)c->d_nkp.p, kp_cap, nA, nseg, (uint2*)c->d_match.p, 0));
+    if (gx_all > gx)
+        hipLaunchKernelGGL(k_match<VO_MATCH_NQ>, dim3(gx_all - gx, nseg, P), dim3(256), 0, st, (const uint8_t*)c->d_desc.p, (const int*)c->d_nkp.p,
+                           kp_cap, nA, nseg, (uint2*)c->d_match.p, gx);
     KT(c, st, VO_K_RATIO, hipLaunchKernelGGL(k_ratio, dim3(P), dim3(1024), 0, st, (const uint2*)c->d_match.p, nseg, (const int*)c->d_nkp.p, kp_cap, nA,
                        (const vo_keypoint*)c->d_kp.p, ratio, pair0, (int4*)c->mq(), (float2*)c->q1(), (float2*)c->q2(),
                        (int*)c->nmatch(), (int*)c->pair_status(), (int2*)c->pair_nkp(), (const int*)c->d_frame_status.p, raw_out));
@@ -343,7 +354,7 @@ extern "C" int vo_match_knn2_ratio_noalloc(vo_ctx* c, const uint8_t* q_dev, int 
     hipLaunchKernelGGL(k_noalloc_setup, dim3(1), dim3(64), 0, st, small, nq, nt);
     if (nq) HIP_TRY(c, hipMemcpyAsync(desc, q_dev, (size_t)nq * 32, hipMemcpyDeviceToDevice, st));
     HIP_TRY(c, hipMemcpyAsync(desc + (long)NA_CAP * 32, t_dev, (size_t)nt * 32, hipMemcpyDeviceToDevice, st));
-    hipLaunchKernelGGL(k_match<VO_MATCH_NQ>, dim3((NA_CAP + 128 * VO_MATCH_NQ - 1) / (128 * VO_MATCH_NQ), NA_NSEG, 1), dim3(256), 0, st, (const uint8_t*)desc, (const int*)small, NA_CAP, 1, NA_NSEG, seg);
+    hipLaunchKernelGGL(k_match<VO_MATCH_NQ>, dim3((NA_CAP + 128 * VO_MATCH_NQ - 1) / (128 * VO_MATCH_NQ), NA_NSEG, 1), dim3(256), 0, st, (const uint8_t*)desc, (const int*)small, NA_CAP, 1, NA_NSEG, seg, 0);
     hipLaunchKernelGGL(k_ratio, dim3(1), dim3(1024), 0, st, (const uint2*)seg, NA_NSEG, (const int*)small, NA_CAP, 1, (const vo_keypoint*)nullptr, ratio, 0, mq,
                        (float2*)nullptr, (float2*)nullptr, small + 4, small + 5, (int2*)(small + 6), (const int*)(small + 2), (int4*)nullptr);
     hipLaunchKernelGGL(k_noalloc_out, dim3((NA_CAP + 255) / 256), dim3(256), 0, st, (const int4*)mq, (const int*)small, cap, (int4*)matches_dev, (int*)n_dev);
