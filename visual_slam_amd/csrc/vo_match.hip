@@ -32,14 +32,13 @@ typedef int v16i __attribute__((ext_vector_type(16)));
 
 // query tiles (of 32) a wavefront keeps in registers.  3: 248 VGPRs, two wavefronts per SIMD.  2 (200 VGPRs, still two per
 // SIMD; every 32-train block's expansion, LDS round trip and barrier then serve 16 instead of 24 MFMAs) measured 86 against
-// 69 us per launch (round 3).
+// 69 us per launch and -3.3 % end to end (round 3).
 #ifndef VO_MATCH_NQ
 #define VO_MATCH_NQ 3
 #endif
 // a launch splits the train set into as few segments as still give this many workgroups (two per CU): every segment repeats the
-// query tiles' load + expansion and a workgroup's loop is only as long as its segment.  32 pairs x 3000: 2 segments of 47 blocks
-// instead of 4 of 24: k_match alone 70 -> 81 us (one round of equal workgroups that run in lock step), but the pipeline +1.4 %
-// (57.1 -> 57.9 k pairs/s, three A/B runs each on one box): half the prologues, half the k_ratio merge reads.
+// query tiles' load + expansion, k_ratio merges the segments, and a workgroup's loop is only as long as its segment.  32 pairs x
+// 3000: 2 segments of 47 blocks instead of 4 of 24: +1.4 % end to end (57.1 -> 57.9 k pairs/s, three A/B runs each on one box).
 #ifndef VO_MATCH_FILL_WGS
 #define VO_MATCH_FILL_WGS 512
 #endif
