@@ -93,6 +93,27 @@ def test_detect_other_sizes_and_params(oracle, kitti02):
         assert np.array_equal(desc, desc_o), (h, w, nf, nl)
 
 
+def test_pyramid_and_blur_levels_whole_on_many_widths(oracle):
+    """Every pyramid level and every blurred level, WHOLE (the descriptor tests only see a blurred level 12 px inside its
+    border), on frame widths of every residue mod 4 and around the 64-px tile boundaries: the lanes at a row's right edge
+    (pulled-back 8-byte window of k_pyramid, reflected dwords of k_blur) and level widths down to 18 px."""
+    from visual_slam_amd import _lib as L, synth
+    sizes = [(64, 64), (65, 70), (66, 99), (67, 64), (127, 80), (128, 65), (129, 131), (191, 64), (257, 100), (258, 67), (259, 75), (260, 90),
+             (319, 201), (383, 70), (449, 133), (511, 64), (513, 77), (640, 96), (1021, 70), (1279, 66)]
+    c = L.Context(max_w=1280, max_h=256, chunk_pairs=1, max_pairs=1)
+    try:
+        for k, (w, h) in enumerate(sizes):
+            img = np.ascontiguousarray(synth.frame_a(np.random.default_rng(300 + k), max(w, 256), max(h, 256))[:h, :w])
+            _, _, dump = oracle.orb_detect_compute(img, debug=True)
+            lw, lh, ofs = _levels(dump)
+            c.orb_detect_compute(img)
+            for l in range(8):
+                assert np.array_equal(c.debug_read(L.VO_DBG_PYR_LEVEL, 0, l), dump["pyr"][ofs[l]:ofs[l + 1]]), ("pyramid", w, h, l, int(lw[l]))
+                assert np.array_equal(c.debug_read(L.VO_DBG_BLUR_LEVEL, 0, l), dump["blurred"][ofs[l]:ofs[l + 1]]), ("blur", w, h, l, int(lw[l]))
+    finally:
+        c.close()
+
+
 def test_flat_image_has_no_keypoints(ctx):
     kps, desc = ctx.orb_detect_compute(np.full((376, 1241), 128, np.uint8))
     assert len(kps) == 0 and desc.shape == (0, 32)
