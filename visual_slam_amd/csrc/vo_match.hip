@@ -262,8 +262,9 @@ __global__ __launch_bounds__(1024) void k_ratio(const uint2* __restrict__ seg_be
     if (tid == 0) { nmatch[gp] = s_running; pair_status[gp] = VO_OK; }
 }
 
-// segments of the train set: at least 4 to fill the chip, and no more than MATCH_SEG_TRAINS trains each
-int vo_match_segments(int kp_cap) { return std::max(4, (kp_cap + MATCH_SEG_TRAINS - 1) / MATCH_SEG_TRAINS); }
+// segments of the train set that d_match has room for: 8 (a single pair then still makes 64 workgroups), and no more than
+// MATCH_SEG_TRAINS trains each
+int vo_match_segments(int kp_cap) { return std::max(8, (kp_cap + MATCH_SEG_TRAINS - 1) / MATCH_SEG_TRAINS); }
 
 // pairs of the chunk: query frame p, train frame nA + p (descriptors of the last detect)
 int vo_launch_match_impl(vo_ctx* c, int P, int nA, double ratio, int pair0, int4* raw_out, hipStream_t st) {
