@@ -205,7 +205,8 @@ __global__ __launch_bounds__(256) void k_pyramid(const Geom* __restrict__ g, Fra
     const uint32_t dofs = (uint32_t)y0 * (uint32_t)L.pitch + (uint32_t)x4;
     static_assert(PYR_ROWS == 4, "one uint4 of row coefficients per lane");
     const uint32_t cyv[PYR_ROWS] = {cy4.x, cy4.y, cy4.z, cy4.w};
-    if (olast + 1 - o0 < 8 && o0 + 8 <= sw) {
+    // every pixel's two taps lie inside the window, or the only one that does not is the right tap of source column sw - 1
+    if ((olast - o0 < 7 || (olast - o0 == 7 && olast == sw - 1)) && o0 + 8 <= sw) {
         uint2 a[PYR_ROWS], b[PYR_ROWS];
 #pragma unroll
         for (int r = 0; r < PYR_ROWS; r++) {
