@@ -231,6 +231,7 @@ int vo_ba_pass(vo_ba_plan* plan, const double* poses, const double* points, cons
 #define VO_DBG_DESCRIPTORS 7    /* frame -> uint8 [n][32] */
 #define VO_DBG_MATCHES 8        /* pair -> int32 [n][4] queryIdx, trainIdx, d1, d2 after ratio */
 #define VO_DBG_E_MASK 9         /* pair -> double E[9] followed by uint8 mask[n_match] */
+#define VO_DBG_VOTES 10         /* pair -> int32 [4]: recoverPose's cheirality counts of [R1|t], [R2|t], [R1|-t], [R2|-t] */
 long vo_debug_read(vo_ctx* ctx, int what, int index, int level, void* out, long bytes);
 /* Parity hook for the five-point minimal solver of vo_find_essential_ransac (no counterpart in the reference's call
  * surface: cv::findEssentialMat runs it internally, modules/calib3d/src/five-point.cpp EMEstimatorCallback::runKernel

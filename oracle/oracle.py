@@ -75,6 +75,9 @@ def lib():
         _lib.orc_recover_pose.argtypes = [
             C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p,
         ]
+        _lib.orc_recover_pose_votes.argtypes = [
+            C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+        ]
         _lib.orc_ratio_filter.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_void_p]
         _lib.orc_pair_run.argtypes = [
             C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p,
@@ -211,6 +214,15 @@ def recover_pose(E, q1, q2, K, dist_thresh=50.0):
     R = np.zeros((3, 3)); t = np.zeros(3); ng = C.c_int(0)
     lib().orc_recover_pose(_ptr(E), _ptr(q1), _ptr(q2), len(q1), _ptr(K), dist_thresh, _ptr(R), _ptr(t), C.byref(ng))
     return R, t, ng.value
+
+
+def recover_pose_votes(E, q1, q2, K, dist_thresh=50.0):
+    """recover_pose plus the cheirality counts of the four candidates [R1|t], [R2|t], [R1|-t], [R2|-t] (int32 [4])."""
+    q1 = np.ascontiguousarray(q1, np.float32).reshape(-1, 2); q2 = np.ascontiguousarray(q2, np.float32).reshape(-1, 2)
+    E = np.ascontiguousarray(E, np.float64); K = np.ascontiguousarray(K, np.float64)
+    R = np.zeros((3, 3)); t = np.zeros(3); ng = C.c_int(0); votes = np.zeros(4, np.int32)
+    lib().orc_recover_pose_votes(_ptr(E), _ptr(q1), _ptr(q2), len(q1), _ptr(K), dist_thresh, _ptr(R), _ptr(t), C.byref(ng), _ptr(votes))
+    return R, t, ng.value, votes
 
 
 def triangulate_f32(P1, P2, x1, x2):

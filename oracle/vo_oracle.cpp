@@ -1107,8 +1107,8 @@ int orc_find_essential_ransac(const float* q1, const float* q2, int n, const dou
 }
 
 /* libs/vo_utils.py:143 -> recoverPose(E, points1, points2, cameraMatrix, R, t) (A.4) */
-int orc_recover_pose(const double E[9], const float* q1, const float* q2, int n, const double K[9], double dist_thresh,
-                     double R[9], double t[3], int* n_good) {
+static int recover_pose_impl(const double E[9], const float* q1, const float* q2, int n, const double K[9], double dist_thresh,
+                             double R[9], double t[3], int* n_good, int votes[4]) {
     double fx = K[0], fy = K[4], cx = K[2], cy = K[5];
     std::vector<double> m1, m2;
     normalize_points(q1, n, fx, fy, cx, cy, m1);
@@ -1154,7 +1154,19 @@ int orc_recover_pose(const double E[9], const float* q1, const float* q2, int n,
     std::memcpy(R, (sel & 1) ? R2 : R1, 9 * sizeof(double));
     for (int i = 0; i < 3; i++) t[i] = (sel >= 2 ? -1.0 : 1.0) * tv[i];
     if (n_good) *n_good = good[sel];
+    if (votes) std::memcpy(votes, good, sizeof(good));
     return 0;
+}
+
+int orc_recover_pose(const double E[9], const float* q1, const float* q2, int n, const double K[9], double dist_thresh,
+                     double R[9], double t[3], int* n_good) {
+    return recover_pose_impl(E, q1, q2, n, K, dist_thresh, R, t, n_good, nullptr);
+}
+
+/* the same call, also returning the four candidates' counts (test hook: the GPU derives two of them) */
+int orc_recover_pose_votes(const double E[9], const float* q1, const float* q2, int n, const double K[9], double dist_thresh,
+                           double R[9], double t[3], int* n_good, int votes[4]) {
+    return recover_pose_impl(E, q1, q2, n, K, dist_thresh, R, t, n_good, votes);
 }
 
 /* libs/vo_utils.py:160 -> triangulatePoints (A.5) */

@@ -104,6 +104,9 @@ void orc_set_pose_variant(int hypot_mode, int ainv_mode);
 /* cv::recoverPose(E, q1, q2, K, R, t) -- no input mask, distanceThresh given. */
 int orc_recover_pose(const double E[9], const float* q1, const float* q2, int n, const double K[9],
                      double dist_thresh, double R[9], double t[3], int* n_good);
+/* the same, also returning the cheirality counts of the four candidates [R1|t], [R2|t], [R1|-t], [R2|-t] (test hook) */
+int orc_recover_pose_votes(const double E[9], const float* q1, const float* q2, int n, const double K[9],
+                           double dist_thresh, double R[9], double t[3], int* n_good, int votes[4]);
 
 /* cv::triangulatePoints for float32 points (2 floats per point, n points): X4 is [4][n]
  * float32, as cv2 returns for float32 inputs. */

@@ -102,6 +102,30 @@ def test_ransac_matches_oracle(ctx, oracle, K02):
         assert rot_angle(Ro, Rg) < 1e-6 and dir_angle(to, tg) < 1e-6   # north-star bound is 1e-3 rad
 
 
+def test_all_four_cheirality_counts_match_the_oracle(ctx, oracle, K02):
+    """recoverPose (libs/vo_utils.py:143) counts, for each of [R1|t], [R2|t], [R1|-t], [R2|-t], the matches that triangulate
+    in front of both cameras.  The GPU triangulates with +t only and derives the -t counts from the sign symmetry of the
+    Jacobi SVD; the oracle triangulates all four.  Same E in, all four counts equal -- on clean scenes,
+    on scenes that are mostly outliers (every candidate gets votes) and with a depth threshold that cuts through the points."""
+    from visual_slam_amd import _lib as L
+    rng = np.random.default_rng(77)
+    nonzero = np.zeros(4, np.int64)
+    for k in range(40):
+        n = int(rng.integers(8, 1500))
+        x1, x2, R, t, _ = two_view(100 + k, n, K02, noise=float(rng.uniform(0, 1.0)), outliers=int(n * rng.uniform(0, 0.9)))
+        if k % 4 == 3:          # pure garbage correspondences
+            x2 = rng.uniform(0, 1200, x2.shape).astype(np.float32)
+        E, _, _ = ctx.find_essential_ransac(x1, x2, K02)
+        dist = 50.0 if k % 3 else float(rng.uniform(2, 30))
+        Ro, to, go, votes_o = oracle.recover_pose_votes(E, x1, x2, K02, dist)
+        Rg, tg, gg = ctx.recover_pose(E, x1, x2, K02, dist)
+        votes_g = ctx.debug_read(L.VO_DBG_VOTES, 0, 0, np.int32)
+        assert np.array_equal(votes_g, votes_o), (k, n, votes_g, votes_o)
+        assert gg == go and np.array_equal(Rg, Ro) and np.array_equal(np.ravel(tg), np.ravel(to)), k
+        nonzero += votes_o > 0
+    assert (nonzero >= 5).all(), nonzero          # every candidate did collect votes in several scenes
+
+
 def test_ransac_degenerate_counts(ctx, oracle, K02):
     from visual_slam_amd._lib import VoError, VO_ERR_TOO_FEW
     x1, x2, *_ = two_view(0, 4, K02)

@@ -14,7 +14,7 @@ SO_PATH = os.environ.get("VO_MI355_LIB") or os.path.join(_HERE, "libvo_mi355.so"
 VO_OK, VO_ERR_INVALID, VO_ERR_HIP, VO_ERR_CAPACITY, VO_ERR_TOO_FEW, VO_ERR_NO_MODEL = 0, -1, -2, -3, -4, -5
 
 VO_DBG_PYR_LEVEL, VO_DBG_BLUR_LEVEL, VO_DBG_FAST_LIST, VO_DBG_SEL1_LIST, VO_DBG_SEL1_HARRIS = 1, 2, 3, 4, 5
-VO_DBG_KEYPOINTS, VO_DBG_DESCRIPTORS, VO_DBG_MATCHES, VO_DBG_E_MASK = 6, 7, 8, 9
+VO_DBG_KEYPOINTS, VO_DBG_DESCRIPTORS, VO_DBG_MATCHES, VO_DBG_E_MASK, VO_DBG_VOTES = 6, 7, 8, 9, 10
 VO_N_KERNELS = 14
 KERNEL_NAMES = ["k_pyramid", "k_fast_tiles", "k_fast_scan", "k_fast_emit", "k_select#1", "k_harris", "k_select#2", "k_orient",
                 "k_blur", "k_rbrief", "k_match", "k_ratio", "ransac(stage)", "recover_pose(stage)"]

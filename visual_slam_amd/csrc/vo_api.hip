@@ -1065,6 +1065,11 @@ long vo_debug_read(vo_ctx* c, int what, int index, int level, void* out, long by
             }
             return have;
         }
+        case VO_DBG_VOTES: {
+            if (index < 0 || index >= c->last_pairs) return VO_ERR_INVALID;
+            if (out && bytes >= 16 && hipMemcpy(out, (const int*)c->d_vote.p + 4L * index, 16, hipMemcpyDeviceToHost) != hipSuccess) return VO_ERR_HIP;
+            return 16;
+        }
     }
     return VO_ERR_INVALID;
 }

@@ -1142,7 +1142,7 @@ __device__ void triangulate_one(const double* P1, const double* P2, double x1, d
 // rows), the row norms W and every convergence test are the same, and IEEE negation is exact.  So the last right singular
 // vector is X' = +-(X0, X1, X2, -X3) bit for bit, and the primed tests follow from the unprimed quantities:
 // X2' X3' = -(X2 X3), Q' = -Q (Q3' = Q3), z' = -z.  Half of the 4 x 4 SVDs (round 3: 13.8 M -> 6.9 M instructions per 32 pairs);
-// the pose tests compare n_good with the oracle, which triangulates all four candidates separately.
+// tests/test_gpu_pose.py compares all four counts with a CPU restatement that triangulates the four candidates separately.
 __global__ __launch_bounds__(64) void k_cheirality(const PoseWork* __restrict__ pw, const int* __restrict__ nmatch, int kp_cap,
                                                     const float2* __restrict__ q1, const float2* __restrict__ q2, NormK nk, double dist_thresh,
                                                     int* __restrict__ vote) {
