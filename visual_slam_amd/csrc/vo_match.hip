@@ -8,55 +8,45 @@
 // k_match computes the distance matrix on the matrix cores.  With train bits a in {0,1} and query
 // bits b recoded as (1 - 2b) in {+1,-1}, one 32x32 tile of Hamming distances is
 //     D[t][q] = |b_q| + sum_k a_tk (1 - 2 b_qk) = |a_t| + |b_q| - 2 a_t.b_q
-// i.e. 8 x v_mfma_i32_32x32x32_i8 (K = 256).  A wavefront keeps MM_NQ query tiles (B operands,
-// expanded once) in registers; the 4 wavefronts of a workgroup share each 32-train block: every
-// lane loads ONE packed dword, expands its 32 bits to 0/1 bytes (2.4 VALU ops per 4 bits) and
-// stores them to a double-buffered LDS image that all wavefronts read back as MFMA A operands
-// (ds_read_b128, conflict free), so HBM/L2 only ever see packed descriptors.
-// The operand bytes are scaled to 64 (a in {0,64}, b in {+64,-64}), so the MFMA sum is 4096 x the
-// distance term and the low 12 bits of the accumulator are free: it is preloaded with
-// 4096*256 + 0x800 + row, and the MFMA result IS the packed key (biased distance << 12 | biased
-// block-relative trainIdx), whose unsigned order is the lexicographic (distance, trainIdx)
-// order.  The accumulator layout puts one query on a lane and 16 trains in its registers, so
-// the 2-NN scan is 2 VALU ops per distance (v_med3_u32, v_min_u32), issued in the shadow of the
-// next tile's MFMAs.  The running keys are re-based by -32 per block so the preload never
-// changes (at most 64 blocks per segment).  The train set is split into segments (grid.y);
-// k_ratio merges the segments, applies the ratio test in Python-double arithmetic and compacts
-// the survivors in ascending query order.
+// i.e. a K = 256 contraction: 4 x v_mfma_scale_f32_32x32x64_f8f6f4 with fp4 (E2M1) operands (round 3; rounds 1-2 used 8 x
+// v_mfma_i32_32x32x32_i8, which runs 32 k per 38 cycles where the fp4 form runs 64 k per 45, tools/ubench_mfma_fp4.hip).
+// A set train bit is the nibble 0x2 (1.0), a query bit the nibble 0x2 / 0xA (+1 / -1), and both block scales are 2^6, so a
+// product is 4096 and the low 12 bits of the sum are free: the f32 accumulator is preloaded with 4096*256 + 0x800 + row --
+// every value an integer below 2^24, so the arithmetic is exact -- and the MFMA result IS the packed key (biased distance
+// << 12 | biased block-relative trainIdx).  Keys are positive floats, whose bit patterns order like the integers they hold:
+// the order of the raw bits is the lexicographic (distance, trainIdx) order, +inf is the sentinel, the re-basing by -32 per
+// block (so that the preload never changes; at most 64 blocks per segment) is an exact float subtraction.
+// A wavefront keeps MM_NQ query tiles (B operands, expanded once, 16 VGPRs each) in registers; the 4 wavefronts of a workgroup
+// share each 32-train block: every lane loads ONE packed dword, expands its 32 bits to nibbles and stores them to a
+// double-buffered LDS image (8 regions of 528 B per block) that all wavefronts read back as MFMA A operands (ds_read_b128), so
+// HBM/L2 only ever see packed descriptors.  The accumulator layout puts one query on a lane and 16 trains in its registers, so
+// the 2-NN scan is 2 VALU ops per distance (v_med3_u32, v_min_u32), scheduled between the next tile's MFMAs.  The train set
+// is split into segments (grid.y); k_ratio merges the segments, applies the ratio test in Python-double arithmetic and
+// compacts the survivors in ascending query order.
+// Lane map of the instruction (checked on exact data by tools/ubench_mfma_fp4.hip): lane (n, h) holds row / column n,
+// k = 32 h + j as nibble j of its four operand dwords; D as every 32 x 32 MFMA.  k-step s of half h is dword 4 h + s of the
+// descriptor (any k order works as long as both operands use it).
 #include <algorithm>
 
 #include "vo_internal.h"
 
 typedef int v4i __attribute__((ext_vector_type(4)));
-typedef int v16i __attribute__((ext_vector_type(16)));
+typedef int v8i __attribute__((ext_vector_type(8)));
+typedef float v16f __attribute__((ext_vector_type(16)));
 
-// query tiles (of 32) a wavefront keeps in registers.  3: 248 VGPRs, two wavefronts per SIMD.  2 (200 VGPRs, still two per
-// SIMD; every 32-train block's expansion, LDS round trip and barrier then serve 16 instead of 24 MFMAs) measured 86 against
-// 69 us per launch and -3.3 % end to end (round 3).
+// query tiles (of 32) a wavefront keeps in registers: 3 = 158 VGPRs, three wavefronts per SIMD.  4 / 5 / 6 tiles (178 / 200 / 231
+// VGPRs, two per SIMD; more MFMAs per barrier) measured 59 / 50 / 45.5 us alone against 48.3 us, all the same end to end.
 #ifndef VO_MATCH_NQ
 #define VO_MATCH_NQ 3
 #endif
-// a launch splits the train set into as few segments as still give this many workgroups (two per CU): every segment repeats the
-// query tiles' load + expansion, k_ratio merges the segments, and a workgroup's loop is only as long as its segment.  32 pairs x
+// a launch splits the train set into as few segments as still give this many workgroups: every segment repeats the query
+// tiles' load + expansion, k_ratio merges the segments, and a workgroup's loop is only as long as its segment.  32 pairs x
 // 3000: 2 segments of 47 blocks instead of 4 of 24: +1.4 % end to end (57.1 -> 57.9 k pairs/s, three A/B runs each on one box).
 #ifndef VO_MATCH_FILL_WGS
 #define VO_MATCH_FILL_WGS 512
 #endif
 #define MATCH_SEG_TRAINS 2016         // trains per segment: 63 blocks of 32 (12-bit block-relative index)
-#define MM_QPB (4 * MM_NQ * 32)      // queries per 256-thread block (MM_NQ 32-query tiles per wavefront)
-#define MM_REGION 528                // LDS bytes per (k-step, half) region: 32 trains x 16 B + 16 B pad
-#define MM_BUF (16 * MM_REGION)
 #define BYTE(d, k) (((d) >> (8 * (k))) & 0xFFu)
-
-// nibble x (0..15) -> dword whose byte i is 64 * bit i of x
-__device__ __forceinline__ uint32_t spread4(uint32_t x) { return (__umul24(x, 0x204081u) << 6) & 0x40404040u; }
-
-// 32 descriptor bits -> two k-steps of 16 bytes (0/64): bits [0,16) and [16,32)
-__device__ __forceinline__ void expand_dword(uint32_t w, v4i& s0, v4i& s1) {
-    const uint32_t lo = w & 0x0F0F0F0Fu, hi = (w >> 4) & 0x0F0F0F0Fu;
-    s0 = v4i{(int)spread4(BYTE(lo, 0)), (int)spread4(BYTE(hi, 0)), (int)spread4(BYTE(lo, 1)), (int)spread4(BYTE(hi, 1))};
-    s1 = v4i{(int)spread4(BYTE(lo, 2)), (int)spread4(BYTE(hi, 2)), (int)spread4(BYTE(lo, 3)), (int)spread4(BYTE(hi, 3))};
-}
 
 __device__ __forceinline__ void key_update(uint32_t key, uint32_t& k1, uint32_t& k2) {
     // k1 <= k2: the new second-smallest is the median of (key, k1, k2); this form selects v_med3_u32
@@ -64,86 +54,89 @@ __device__ __forceinline__ void key_update(uint32_t key, uint32_t& k1, uint32_t&
     k1 = min(k1, key);
 }
 
+#define MM_QPB (4 * MM_NQ * 32)
+#define MM_REGION 528                // LDS bytes per (k-step, half) region: 32 trains x 16 B + 16 B pad
+#define MM_BUF (8 * MM_REGION)
+
+// 8 descriptor bits -> 8 nibbles, nibble j = 2 * bit j (E2M1 1.0 for a set bit)
+__device__ __forceinline__ uint32_t spread8_nib(uint32_t x) {
+    uint32_t t = (x | (x << 12)) & 0x000F000Fu;
+    t = (t | (t << 6)) & 0x03030303u;
+    t = (t | (t << 3)) & 0x11111111u;
+    return t << 1;
+}
+__device__ __forceinline__ v4i expand_dword4(uint32_t w) {
+    return v4i{(int)spread8_nib(BYTE(w, 0)), (int)spread8_nib(BYTE(w, 1)), (int)spread8_nib(BYTE(w, 2)), (int)spread8_nib(BYTE(w, 3))};
+}
+__device__ __forceinline__ v16f mfma4(const v4i& a, const v4i& b, const v16f& c) {
+    const v8i a8 = {a[0], a[1], a[2], a[3], 0, 0, 0, 0}, b8 = {b[0], b[1], b[2], b[3], 0, 0, 0, 0};
+    return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, c, 4, 4, 0, 133, 0, 133);   // fp4 x fp4, scales 2^(133 - 127)
+}
+
+// (v_min_f32 -- full rate where v_min_u32 is half rate, and the same order on these keys -- was tried for the scan through inline
+// asm: 49.9 against 48.9 us, no gain; and an asm statement that reads an MFMA result gets no hazard wait states from the compiler:
+// scheduled ahead of the v_med3 it read stale registers.)
 template <int MM_NQ>
 __global__ __launch_bounds__(256) void k_match(const uint8_t* __restrict__ desc, const int* __restrict__ nkp, int kp_cap, int nA,
-                                               int nseg, uint2* __restrict__ seg_best, int xb0) {
+                                                int nseg, uint2* __restrict__ seg_best, int xb0) {
     __shared__ __attribute__((aligned(16))) uint8_t abuf[2 * MM_BUF];
     const int p = blockIdx.z, seg = blockIdx.y;
     const int qf = p, tf = nA + p;
     const int nq = nkp[qf], nt = nkp[tf];
-    const int xb = (int)blockIdx.x + xb0;   // query block (a launch covers the blocks xb0 .. xb0 + gridDim.x - 1)
+    const int xb = (int)blockIdx.x + xb0;
     if (xb * MM_QPB >= nq) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 31, h = lane >> 5;
     const int q0 = xb * MM_QPB + wave * (MM_NQ * 32);
-    // query tiles: lane (n, h) holds half h of query q0 + 32u + n, recoded to +1 / -1; k-step s = bits [16s, 16s+16) of the half
-    v4i B[MM_NQ][8];
+    v4i B[MM_NQ][4];
     int pc[MM_NQ];
 #pragma unroll
     for (int u = 0; u < MM_NQ; u++) {
         const int q = min(q0 + 32 * u + n, nq - 1);
         const uint4 raw = *reinterpret_cast<const uint4*>(desc + ((long)qf * kp_cap + q) * 32 + 16 * h);
-        expand_dword(raw.x, B[u][0], B[u][1]);
-        expand_dword(raw.y, B[u][2], B[u][3]);
-        expand_dword(raw.z, B[u][4], B[u][5]);
-        expand_dword(raw.w, B[u][6], B[u][7]);
+        const uint32_t rw[4] = {raw.x, raw.y, raw.z, raw.w};
 #pragma unroll
-        for (int s = 0; s < 8; s++)
+        for (int s = 0; s < 4; s++) {
+            B[u][s] = expand_dword4(rw[s]);
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const uint32_t x = (uint32_t)B[u][s][j];
-                B[u][s][j] = (int)((x << 1) | 0x40404040u);   // byte 64 -> 0xC0 (-64), byte 0 -> 0x40 (+64)
-            }
+            for (int j = 0; j < 4; j++) B[u][s][j] = (int)(((uint32_t)B[u][s][j] << 2) | 0x22222222u);   // bit 1 -> 0xA (-1), bit 0 -> 0x2 (+1)
+        }
         const int half = __popc(raw.x) + __popc(raw.y) + __popc(raw.z) + __popc(raw.w);
         pc[u] = half + __shfl_xor(half, 32);
     }
     uint32_t k1[MM_NQ], k2[MM_NQ];
 #pragma unroll
-    for (int u = 0; u < MM_NQ; u++) k1[u] = k2[u] = 0xFFFFFFFFu;
-    const int per = (((nt + nseg - 1) / nseg) + 31) & ~31;   // multiple of 32: only the last segment has a ragged block
+    for (int u = 0; u < MM_NQ; u++) k1[u] = k2[u] = 0x7F800000u;   // +inf
+    const int per = (((nt + nseg - 1) / nseg) + 31) & ~31;
     const int t0 = seg * per, t1 = min(t0 + per, nt);
     const int nblk = t0 < t1 ? (t1 - t0 + 31) >> 5 : 0;
     if (nblk > 0) {   // uniform over the workgroup
-        // register i of lane (n, h) is train row (i&3) + 8(i>>2) + 4h of the block; the lane-constant 4h is added after the loop
-        v16i cinit;
+        v16f cinit;
 #pragma unroll
-        for (int i = 0; i < 16; i++) cinit[i] = 4096 * 256 + 0x800 + (i & 3) + 8 * (i >> 2);
-        // producer role: thread tid owns dword (tid & 7) of train (tid >> 3) of the block:
-        // half = dword >> 2, k-steps 2(dword & 3) and 2(dword & 3) + 1
+        for (int i = 0; i < 16; i++) cinit[i] = (float)(4096 * 256 + 0x800 + (i & 3) + 8 * (i >> 2));
+        // producer role: thread tid owns dword (tid & 7) of train (tid >> 3) of the block: half = dword >> 2, k-step = dword & 3
         const int pm = tid >> 3, pd = tid & 7;
         const uint32_t* tp = reinterpret_cast<const uint32_t*>(desc + (long)tf * kp_cap * 32) + pd;
-        uint8_t* wr = abuf + ((4 * (pd & 3) + (pd >> 2)) * MM_REGION + pm * 16);   // region index = 2 * kstep + half
+        uint8_t* wr = abuf + ((2 * (pd & 3) + (pd >> 2)) * MM_REGION + pm * 16);   // region index = 2 * kstep + half
         const uint8_t* rd = abuf + h * MM_REGION + n * 16;
-        {
-            v4i s0, s1;
-            expand_dword(tp[(long)min(t0 + pm, nt - 1) * 8], s0, s1);
-            *reinterpret_cast<v4i*>(wr) = s0;
-            *reinterpret_cast<v4i*>(wr + 2 * MM_REGION) = s1;
-        }
+        *reinterpret_cast<v4i*>(wr) = expand_dword4(tp[(long)min(t0 + pm, nt - 1) * 8]);
         uint32_t raw = nblk > 1 ? tp[(long)min(t0 + 32 + pm, nt - 1) * 8] : 0u;
         __syncthreads();
-        v4i A0[8], A1[8];
+        v4i A0[4], A1[4];
 #pragma unroll
-        for (int s = 0; s < 8; s++) A0[s] = *reinterpret_cast<const v4i*>(rd + 2 * s * MM_REGION);
-        // Software pipeline over the tiles (block, u): the 8 MFMAs of a tile are interleaved, two results per
-        // MFMA, with the 2-NN scan of the PREVIOUS tile, so matrix and vector pipes run together inside one
-        // wavefront.  accP is the previous tile's result; it starts as "all sentinels".
-        v16i accP;
+        for (int s = 0; s < 4; s++) A0[s] = *reinterpret_cast<const v4i*>(rd + 2 * s * MM_REGION);
+        v16f accP;
 #pragma unroll
-        for (int i = 0; i < 16; i++) accP[i] = -1;
-        auto block = [&](v4i (&Ac)[8], v4i (&An)[8], int it) {
+        for (int i = 0; i < 16; i++) accP[i] = __uint_as_float(0x7F800000u);
+        auto block = [&](v4i (&Ac)[4], v4i (&An)[4], int it) {
             if (it + 1 < nblk) {
-                v4i s0, s1;
-                expand_dword(raw, s0, s1);
-                uint8_t* w2 = wr + ((it + 1) & 1) * MM_BUF;
-                *reinterpret_cast<v4i*>(w2) = s0;
-                *reinterpret_cast<v4i*>(w2 + 2 * MM_REGION) = s1;
+                *reinterpret_cast<v4i*>(wr + ((it + 1) & 1) * MM_BUF) = expand_dword4(raw);
                 if (it + 2 < nblk) raw = tp[(long)min(t0 + 32 * it + 64 + pm, nt - 1) * 8];
             } else if (t0 + 32 * nblk > t1) {
                 // ragged last block: rows at or beyond t1 get +1024 on the distance, which reads as a sentinel
 #pragma unroll
                 for (int i = 0; i < 16; i++)
-                    if (t0 + 32 * it + (i & 3) + 8 * (i >> 2) + 4 * h >= t1) cinit[i] += 4096 * 1024;
+                    if (t0 + 32 * it + (i & 3) + 8 * (i >> 2) + 4 * h >= t1) cinit[i] += (float)(4096 * 1024);
             }
 #pragma unroll
             for (int u = 0; u < MM_NQ; u++) {
@@ -152,25 +145,24 @@ __global__ __launch_bounds__(256) void k_match(const uint8_t* __restrict__ desc,
                     if (it + 1 < nblk) {
                         const uint8_t* r2 = rd + ((it + 1) & 1) * MM_BUF;
 #pragma unroll
-                        for (int s = 0; s < 8; s++) An[s] = *reinterpret_cast<const v4i*>(r2 + 2 * s * MM_REGION);
+                        for (int s = 0; s < 4; s++) An[s] = *reinterpret_cast<const v4i*>(r2 + 2 * s * MM_REGION);
                     }
                 }
                 const int up = (u + MM_NQ - 1) % MM_NQ;    // the previous tile's query tile
-                k1[up] -= 32;   // re-base its running keys to the block of accP (the sentinel stays above every real key)
-                k2[up] -= 32;
-                // source order = issue order: one MFMA, then six VALU ops of the previous tile's scan in its shadow
-                v16i acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(Ac[0], B[u][0], cinit, 0, 0, 0);
-                key_update((uint32_t)accP[0], k1[up], k2[up]);
-                key_update((uint32_t)accP[1], k1[up], k2[up]);
-                asm volatile("" : "+v"(k1[up]), "+v"(k2[up]));   // keeps the scan ops here (no sinking past the barrier)
-                __builtin_amdgcn_sched_barrier(0);
+                k1[up] = __float_as_uint(__uint_as_float(k1[up]) - 32.f);   // re-base to the block of accP (inf stays inf)
+                k2[up] = __float_as_uint(__uint_as_float(k2[up]) - 32.f);
+                // four MFMAs and the 32 VALU ops of the previous tile's scan; the group barriers ask the scheduler for
+                // MFMA, 8 VALU, MFMA, 8 VALU ... (the MFMA intrinsic is free to move at the IR level, so source order alone
+                // does not hold it in place)
+                v16f acc = mfma4(Ac[0], B[u][0], cinit);
 #pragma unroll
-                for (int s = 1; s < 8; s++) {
-                    acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(Ac[s], B[u][s], acc, 0, 0, 0);
-                    key_update((uint32_t)accP[2 * s], k1[up], k2[up]);
-                    key_update((uint32_t)accP[2 * s + 1], k1[up], k2[up]);
-                    asm volatile("" : "+v"(k1[up]), "+v"(k2[up]));
-                    __builtin_amdgcn_sched_barrier(0);
+                for (int s = 1; s < 4; s++) acc = mfma4(Ac[s], B[u][s], acc);
+#pragma unroll
+                for (int i = 0; i < 16; i++) key_update(__float_as_uint(accP[i]), k1[up], k2[up]);
+#pragma unroll
+                for (int s = 0; s < 4; s++) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);   // eight VALU
                 }
                 accP = acc;
             }
@@ -179,18 +171,18 @@ __global__ __launch_bounds__(256) void k_match(const uint8_t* __restrict__ desc,
             block(A0, A1, it);
             if (it + 1 < nblk) block(A1, A0, it + 1);
         }
-        // drain: the last tile
-        k1[MM_NQ - 1] -= 32;
-        k2[MM_NQ - 1] -= 32;
+        k1[MM_NQ - 1] = __float_as_uint(__uint_as_float(k1[MM_NQ - 1]) - 32.f);
+        k2[MM_NQ - 1] = __float_as_uint(__uint_as_float(k2[MM_NQ - 1]) - 32.f);
 #pragma unroll
-        for (int i = 0; i < 16; i++) key_update((uint32_t)accP[i], k1[MM_NQ - 1], k2[MM_NQ - 1]);
+        for (int i = 0; i < 16; i++) key_update(__float_as_uint(accP[i]), k1[MM_NQ - 1], k2[MM_NQ - 1]);
     }
     uint2* out = seg_best + ((long)p * nseg + seg) * kp_cap;
     const int jlast = t0 + 32 * (nblk - 1);
 #pragma unroll
     for (int u = 0; u < MM_NQ; u++) {
-        // undo the biases: distance = (key >> 12) - 256 + |b_q|, trainIdx = jlast + (key & 0xFFF) - 0x800 + 4h
-        const uint32_t x1 = k1[u], x2 = k2[u];
+        // keys below 2^22 are real: distance = (key >> 12) - 256 + |b_q|, trainIdx = jlast + (key & 0xFFF) - 0x800 + 4h
+        const float f1 = __uint_as_float(k1[u]), f2 = __uint_as_float(k2[u]);
+        const uint32_t x1 = f1 < 4194304.f ? (uint32_t)f1 : 0xFFFFFFFFu, x2 = f2 < 4194304.f ? (uint32_t)f2 : 0xFFFFFFFFu;
         const uint32_t a1 = (x1 >> 22) == 0 ? ((((x1 >> 12) + pc[u] - 256) << 16) + (uint32_t)(jlast + (int)(x1 & 0xFFF) - 0x800 + 4 * h)) : 0xFFFFFFFFu;
         const uint32_t a2 = (x2 >> 22) == 0 ? ((((x2 >> 12) + pc[u] - 256) << 16) + (uint32_t)(jlast + (int)(x2 & 0xFFF) - 0x800 + 4 * h)) : 0xFFFFFFFFu;
         const uint32_t b1 = __shfl_xor(a1, 32), b2 = __shfl_xor(a2, 32);
