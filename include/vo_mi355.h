@@ -223,7 +223,8 @@ int vo_ba_pass(vo_ba_plan* plan, const double* poses, const double* points, cons
  * vo_orb_detect_compute / vo_pairs_run* chunk to host.  `what`: see VO_DBG_*.
  * Returns the number of bytes the buffer holds (copying at most `bytes`). */
 #define VO_DBG_PYR_LEVEL 1      /* frame, level -> tight level image (w_l*h_l bytes) */
-#define VO_DBG_BLUR_LEVEL 2     /* frame, level -> tight blurred level */
+#define VO_DBG_BLUR_LEVEL 2     /* frame, level -> tight blurred level (complete in contexts created with max_pairs = 1; batch
+                                   contexts blur only the 64 x 64 tiles that a descriptor patch reaches) */
 #define VO_DBG_FAST_LIST 3      /* frame, level -> int32 [n][3] x,y,score (raster order) */
 #define VO_DBG_SEL1_LIST 4      /* frame, level -> int32 [n][3] after retainBest(2*quota) */
 #define VO_DBG_SEL1_HARRIS 5    /* frame, level -> float [n] Harris of the SEL1 list */

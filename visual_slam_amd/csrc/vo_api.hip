@@ -124,7 +124,7 @@ static int lane_init(vo_ctx* c, bool with_aux) {
     const long F = c->max_frames, kc = c->kp_cap, CP = c->chunk_pairs;
     // upper bounds from the max image size (all quantities are monotone in w, h)
     const long W = c->max_w, H = c->max_h;
-    long pyr = 0, blur = 0, cand = 0, tiles = 0, segs = 0;
+    long pyr = 0, blur = 0, cand = 0, tiles = 0, segs = 0, btiles = 0;
     {
         const double sf = (double)p.scale_factor;
         for (int l = 0; l < p.nlevels; l++) {
@@ -136,6 +136,7 @@ static int lane_init(vo_ctx* c, bool with_aux) {
             const long iw = std::max(w - 62, 0L), ih = std::max(h - 62, 0L);
             const long ntx = (iw + VO_TILE_W - 1) / VO_TILE_W, nty = (ih + VO_TILE_H - 1) / VO_TILE_H;
             tiles += ntx * nty;
+            btiles += ((w + VO_BLUR_TW - 1) / VO_BLUR_TW) * ((h + VO_BLUR_TH - 1) / VO_BLUR_TH);
             segs += (ih * ntx + 15) / 16 * 16;
             cand += (((iw + 1) / 2) * ((ih + 1) / 2) + 63) / 64 * 64;
         }
@@ -157,10 +158,12 @@ static int lane_init(vo_ctx* c, bool with_aux) {
     ALLOC(c, c->d_kp, (size_t)F * kc * sizeof(vo_keypoint));
     ALLOC(c, c->d_kplvl, (size_t)F * kc * 4);
     ALLOC(c, c->d_desc, (size_t)F * kc * 32);
+    ALLOC(c, c->d_bneed, (size_t)F * (btiles + 8));
     ALLOC(c, c->d_match, (size_t)CP * vo_match_segments(kc) * kc * sizeof(uint2));
     ALLOC(c, c->d_raw, (size_t)kc * sizeof(int4));
     HIP_TRY(c, hipMemset(c->d_frame_status.p, 0, c->d_frame_status.bytes));
     HIP_TRY(c, hipMemset(c->d_kp.p, 0, c->d_kp.bytes));
+    HIP_TRY(c, hipMemset(c->d_bneed.p, 0, c->d_bneed.bytes));
     return VO_OK;
 }
 
@@ -168,7 +171,7 @@ static void lane_free(vo_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->aux_stream) (void)hipStreamSynchronize(c->aux_stream);
     DevBuf* bufs[] = {&c->d_pyr, &c->d_blur, &c->d_tile_list, &c->d_seg_cnt, &c->d_seg_ofs, &c->d_key, &c->d_payload, &c->d_lpos, &c->d_rpos,
-                      &c->d_cnt_fast, &c->d_cnt_sel1, &c->d_cnt_sel2, &c->d_nkp, &c->d_kp, &c->d_kplvl, &c->d_desc, &c->d_frame_status, &c->d_match, &c->d_raw};
+                      &c->d_cnt_fast, &c->d_cnt_sel1, &c->d_cnt_sel2, &c->d_nkp, &c->d_kp, &c->d_kplvl, &c->d_desc, &c->d_frame_status, &c->d_match, &c->d_raw, &c->d_bneed};
     for (DevBuf* b : bufs) dev_free(*b);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);

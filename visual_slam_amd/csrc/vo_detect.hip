@@ -1057,7 +1057,8 @@ __constant__ int c_umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9
 __global__ __launch_bounds__(256) void k_orient(const Geom* __restrict__ g, FrameSrc src, const uint8_t* __restrict__ pyr,
                                                 const int* __restrict__ cnt_sel2, const float* __restrict__ key,
                                                 const uint32_t* __restrict__ payload, vo_keypoint* __restrict__ kps,
-                                                uint32_t* __restrict__ kplvl, int* __restrict__ nkp, int* __restrict__ frame_status, int nframes) {
+                                                uint32_t* __restrict__ kplvl, int* __restrict__ nkp, int* __restrict__ frame_status, int nframes,
+                                                uint8_t* __restrict__ bneed) {
     const VBlock vb = xcd_block(ORIENT_BX, g->nlevels, nframes);
     if (!vb.valid) return;
     const int l = vb.y, f = vb.f;
@@ -1136,6 +1137,14 @@ __global__ __launch_bounds__(256) void k_orient(const Geom* __restrict__ g, Fram
             const long o = (long)f * g->kp_cap + off + i;
             kps[o] = k;
             kplvl[o] = PACK_XYS(x0, y0, l);
+            if (bneed) {
+                // the blur tiles (64 x 64) that this keypoint's descriptor patch reaches: rBRIEF samples within 19 px (RB_R).
+                // Up to four byte stores of the same value; k_blur computes only marked tiles and clears the marks.
+                uint8_t* nb = bneed + (long)f * g->nbtiles + L.btile_base;
+                const int tx0 = max(x0 - 19, 0) / VO_BLUR_TW, tx1 = min(x0 + 19, L.w - 1) / VO_BLUR_TW;
+                const int ty0 = max(y0 - 19, 0) / VO_BLUR_TH, ty1 = min(y0 + 19, L.h - 1) / VO_BLUR_TH;
+                nb[ty0 * L.bntx + tx0] = 1; nb[ty0 * L.bntx + tx1] = 1; nb[ty1 * L.bntx + tx0] = 1; nb[ty1 * L.bntx + tx1] = 1;
+            }
         }
         __syncthreads();
     }
@@ -1166,12 +1175,17 @@ static_assert(VO_BLUR_TH == 16 * BL_RPL && VO_BLUR_TW == 64 && BL_ROWS % 14 == 0
 // MODE (blur_mode) and FMA (vo_orb_params.fma_blur) are template parameters: as run-time flags they left a branch per output pixel.
 template <int MODE, bool FMA>
 __global__ __launch_bounds__(256) void k_blur(const Geom* __restrict__ g, FrameSrc src, const uint8_t* __restrict__ pyr,
-                                              uint8_t* __restrict__ blur, const TileDesc* __restrict__ btiles, BlurK bk, int nframes) {
+                                              uint8_t* __restrict__ blur, const TileDesc* __restrict__ btiles, BlurK bk, int nframes,
+                                              uint8_t* __restrict__ need) {
     __shared__ __attribute__((aligned(16))) uint8_t sp[BL_ROWS * BL_SP];
     __shared__ __attribute__((aligned(16))) float rowf[BL_ROWS * VO_BLUR_TW];
     const VBlock vb = xcd_block(g->nbtiles, 1, nframes);
     if (!vb.valid) return;
     const int f = vb.f, tid = threadIdx.x;
+    // batch contexts: only the tiles that a descriptor patch reaches (k_orient marked them; the mark is cleared below, after the
+    // barrier that follows every thread's read of it).  On real frames a third of the tiles holds no keypoint (sky, road).
+    uint8_t* const mark = need ? need + (long)f * g->nbtiles + vb.x : nullptr;
+    if (mark && *mark == 0) return;
     const TileDesc td = btiles[vb.x];
     const LevelGeom& L = g->lv[td.level];
     int pitch;
@@ -1225,6 +1239,7 @@ __global__ __launch_bounds__(256) void k_blur(const Geom* __restrict__ g, FrameS
         }
     }
     __syncthreads();
+    if (mark && tid == 0) *mark = 0;
     constexpr bool use_fma = FMA;
     constexpr int mode = MODE;
     // the weights live in VGPRs: a VOP2 multiply/fma with an SGPR operand issues at half rate on gfx950 (tools/ubench2.hip)
@@ -1497,10 +1512,14 @@ int vo_launch_detect(vo_ctx* c, const FrameSrc& src, int F, hipStream_t st) {
     auto blur_fn = g.blur_mode == 1 ? k_blur<1, false> : (g.fma_blur ? k_blur<0, true> : k_blur<0, false>);
     static const bool serial = getenv("VO_SERIAL") != nullptr;   // profiling aid: one kernel at a time, so trace durations are per kernel
     const bool fork_blur = !serial && !c->timing && c->debug_stop == 0 && c->aux_stream != nullptr && vo_live_contexts(c->device) <= 2;
+    // Contexts that hold more than one pair blur only the tiles a descriptor patch reaches (the blur then has to come after the
+    // orientation kernel, which marks them: not in the forked arrangement).  A single-pair context blurs whole levels, so that
+    // vo_debug_read(VO_DBG_BLUR_LEVEL) returns complete images there.
+    uint8_t* const bneed = (!fork_blur && c->debug_stop == 0 && c->max_pairs > 1) ? (uint8_t*)c->d_bneed.p : nullptr;
     if (fork_blur) {
         HIP_TRY(c, hipEventRecord(c->ev_fork, st));
         HIP_TRY(c, hipStreamWaitEvent(c->aux_stream, c->ev_fork, 0));
-        hipLaunchKernelGGL(blur_fn, dim3(pad8(g.nbtiles * F)), dim3(256), 0, c->aux_stream, dg, src, pyr, blur, (const TileDesc*)c->d_btiles.p, bk, F);
+        hipLaunchKernelGGL(blur_fn, dim3(pad8(g.nbtiles * F)), dim3(256), 0, c->aux_stream, dg, src, pyr, blur, (const TileDesc*)c->d_btiles.p, bk, F, (uint8_t*)nullptr);
         HIP_TRY(c, hipEventRecord(c->ev_join, c->aux_stream));
     }
     if (g.ntiles > 0) {
@@ -1529,9 +1548,9 @@ int vo_launch_detect(vo_ctx* c, const FrameSrc& src, int F, hipStream_t st) {
     if (c->debug_stop == 2) { HIP_TRY(c, hipGetLastError()); return VO_OK; }
     KT(c, st, VO_K_SELECT2, hipLaunchKernelGGL((k_select<256, 2048>), dim3(g.nlevels, F), dim3(256), 0, st, dg, key, payload, (uint32_t*)c->d_lpos.p, (uint32_t*)c->d_rpos.p, cnt_sel1, cnt_sel2, 1, 0));
     KT(c, st, VO_K_ORIENT, hipLaunchKernelGGL(k_orient, dim3(pad8(ORIENT_BX * g.nlevels * F)), dim3(256), 0, st, dg, src, pyr, cnt_sel2, key, payload, (vo_keypoint*)c->d_kp.p,
-                       (uint32_t*)c->d_kplvl.p, (int*)c->d_nkp.p, (int*)c->d_frame_status.p, F));
+                       (uint32_t*)c->d_kplvl.p, (int*)c->d_nkp.p, (int*)c->d_frame_status.p, F, bneed));
     if (fork_blur) HIP_TRY(c, hipStreamWaitEvent(st, c->ev_join, 0));
-    else KT(c, st, VO_K_BLUR, hipLaunchKernelGGL(blur_fn, dim3(pad8(g.nbtiles * F)), dim3(256), 0, st, dg, src, pyr, blur, (const TileDesc*)c->d_btiles.p, bk, F));
+    else KT(c, st, VO_K_BLUR, hipLaunchKernelGGL(blur_fn, dim3(pad8(g.nbtiles * F)), dim3(256), 0, st, dg, src, pyr, blur, (const TileDesc*)c->d_btiles.p, bk, F, bneed));
     const int rb_nbx = (g.kp_cap + RB_KPB - 1) / RB_KPB;
     KT(c, st, VO_K_RBRIEF, hipLaunchKernelGGL(k_rbrief, dim3(pad8(rb_nbx * F)), dim3(256), 0, st, dg, blur, (const signed char*)c->d_pat.p, (const int*)c->d_nkp.p,
                        (const vo_keypoint*)c->d_kp.p, (const uint32_t*)c->d_kplvl.p, (uint8_t*)c->d_desc.p, rb_nbx, F));

@@ -110,6 +110,7 @@ struct vo_ctx {
     DevBuf d_key, d_payload, d_lpos, d_rpos;
     DevBuf d_cnt_fast, d_cnt_sel1, d_cnt_sel2;   // int [F][L]
     DevBuf d_nkp, d_kp, d_kplvl, d_desc, d_frame_status;
+    DevBuf d_bneed;        // uint8 [F][nbtiles]: blur tiles that a descriptor patch reaches (set by k_orient, consumed by k_blur)
     // matching / pose workspace (per pair)
     DevBuf d_match;        // int4 [P][kp_cap] best/second per query
     DevBuf d_nmatch, d_mq, d_q1, d_q2;
