@@ -750,7 +750,18 @@ def main():
                     batches.append(e0.elapsed_time(e1) / 20)
                 kb["whole_pass"] = float(np.median(batches))
                 kb["batches"] = [round(b, 5) for b in batches]
-            a_ba = ba_bytes / (kb["whole_pass"] * 1e-3) / 1e9
+            # the pass kernel alone, HIP events around its launch on the launch stream (as `roofline` does for the detect kernels):
+            # a pass is two dependent launches, and the gap between them -- 1 to 6 us per boundary from box to box -- is not kernel time
+            plan.set_kernel_timing(True)
+            with torch.cuda.stream(side):
+                for _ in range(20):
+                    plan.run_device(t_p.data_ptr(), t_x.data_ptr(), t_uv.data_ptr(), pr["K"], o_r.data_ptr(), o_n.data_ptr(), o_Hpp.data_ptr(),
+                                    o_bp.data_ptr(), o_Hll.data_ptr(), o_bl.data_ptr(), o_Hpl.data_ptr(), stream=side.cuda_stream)
+            kt_ba = plan.kernel_timing()
+            plan.set_kernel_timing(False)
+            kb["k_ba_pass"] = kt_ba["k_ba_pass"][0] / max(kt_ba["k_ba_pass"][1], 1)
+            kb["k_ba_rot"] = kt_ba["k_ba_rot"][0] / max(kt_ba["k_ba_rot"][1], 1)
+            a_ba = ba_bytes / (kb["k_ba_pass"] * 1e-3) / 1e9
             ba_traffic = None
             try:        # the committed FETCH_SIZE / WRITE_SIZE passes describe the whole configs[4] problem on one rank
                 with open(BA_TRAFFIC_FILE) as f:
@@ -760,8 +771,10 @@ def main():
             except Exception:
                 pass
             ba_out["roofline"] = {"bound": "hbm", "achieved": round(a_ba, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(a_ba / HBM_PEAK_GBS, 4), "traffic": ba_traffic,
-                                  "bytes_per_pass": int(ba_bytes), "device_ms_per_pass": round(kb["whole_pass"], 5), "device_ms_per_pass_batches": kb["batches"],
-                                  "note": "HIP events on the launch stream, median of 7 batches of 20 passes back to back (k_ba_rot + k_ba_pass per pass; kernel durations: profiles/r3_*_ba_kernel_stats.csv); ms_per_pass above is host wall clock per synchronous call (+ the all-reduce at N > 1)"}
+                                  "bytes_per_pass": int(ba_bytes), "kernel": "k_ba_pass", "avg_launch_ms": round(kb["k_ba_pass"], 5), "k_ba_rot_avg_launch_ms": round(kb["k_ba_rot"], 5),
+                                  "device_ms_per_pass": round(kb["whole_pass"], 5), "device_ms_per_pass_batches": kb["batches"],
+                                  "frac_of_whole_pass": round(ba_bytes / (kb["whole_pass"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                  "note": "achieved / frac: the algorithmic bytes of a pass over the average duration of k_ba_pass, HIP events around its launch (20 launches); device_ms_per_pass: median of 7 batches of 20 passes back to back, which adds k_ba_rot and the two launch boundaries (k_ba_rot + k_ba_pass per pass; kernel durations: profiles/r3_*_ba_kernel_stats.csv); ms_per_pass above is host wall clock per synchronous call (+ the all-reduce at N > 1)"}
         plan.close()
 
     cpu = None

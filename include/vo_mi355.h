@@ -215,6 +215,11 @@ void vo_ba_plan_destroy(vo_ba_plan* plan);
 int vo_ba_pass_device(vo_ba_plan* plan, const double* poses_dev, const double* points_dev, const double* uv_dev,
                       const double K[9], double* r_dev, double* norm_dev, double* Hpp_dev, double* bp_dev,
                       double* Hll_dev, double* bl_dev, double* Hpl_dev, void* stream);
+/* Diagnostic, as vo_set_kernel_timing for the detect kernels: with timing on, vo_ba_pass_device brackets each of its two
+ * launches with HIP events on the launch stream and waits for them; vo_ba_get_kernel_timing returns the accumulated
+ * milliseconds and launch counts of k_ba_rot and k_ba_pass (ms[2], launches[2]) since timing was switched on. */
+int vo_ba_set_kernel_timing(vo_ba_plan* plan, int on);
+int vo_ba_get_kernel_timing(vo_ba_plan* plan, double ms[2], int launches[2]);
 /* host pointers (adds the copies) */
 int vo_ba_pass(vo_ba_plan* plan, const double* poses, const double* points, const double* uv, const double K[9],
                double* r, double* norm, double* Hpp, double* bp, double* Hll, double* bl, double* Hpl);

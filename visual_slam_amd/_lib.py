@@ -35,7 +35,7 @@ PAIR_DTYPE = np.dtype([("T", "<f8", (4, 4)), ("n_kp1", "<i4"), ("n_kp2", "<i4"),
 # every symbol include/vo_mi355.h declares
 EXPORTS = [
     "vo_default_orb_params", "vo_ctx_create", "vo_ctx_destroy", "vo_last_error", "vo_orb_detect_compute", "vo_match_knn2_ratio",
-    "vo_match_knn2", "vo_find_essential_ransac", "vo_recover_pose", "vo_triangulate", "vo_pairs_run_device", "vo_pairs_run", "vo_sequence_run_device", "vo_sequence_run", "vo_ba_plan_create", "vo_ba_plan_destroy", "vo_ba_pass_device", "vo_ba_pass",
+    "vo_match_knn2", "vo_find_essential_ransac", "vo_recover_pose", "vo_triangulate", "vo_pairs_run_device", "vo_pairs_run", "vo_sequence_run_device", "vo_sequence_run", "vo_ba_plan_create", "vo_ba_plan_destroy", "vo_ba_pass_device", "vo_ba_pass", "vo_ba_set_kernel_timing", "vo_ba_get_kernel_timing",
     "vo_match_knn2_ratio_noalloc", "vo_get_matches", "vo_get_pose", "vo_pairs_triangulate", "vo_pairs_submit_device", "vo_sequence_submit_device", "vo_pairs_wait", "vo_debug_read", "vo_debug_minimal_solver", "vo_set_debug_stop", "vo_set_kernel_timing", "vo_get_kernel_timing",
 ]
 
@@ -85,6 +85,8 @@ def load():
     lib.vo_ba_plan_destroy.restype = None
     lib.vo_ba_pass_device.argtypes = [vp] * 13
     lib.vo_ba_pass.argtypes = [vp] * 12
+    lib.vo_ba_set_kernel_timing.argtypes = [vp, i]
+    lib.vo_ba_get_kernel_timing.argtypes = [vp, vp, vp]
     lib.vo_debug_read.argtypes = [vp, i, i, i, vp, C.c_long]
     lib.vo_debug_read.restype = C.c_long
     lib.vo_debug_minimal_solver.argtypes = [vp, i, vp, i, vp]

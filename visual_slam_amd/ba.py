@@ -97,6 +97,18 @@ class BAPlan:
             raise _lib.VoError(rc, "vo_ba_pass failed")
         return out
 
+    def set_kernel_timing(self, on):
+        """Diagnostic: bracket each launch of run_device with HIP events (the calls then wait for their kernels)."""
+        if self.lib.vo_ba_set_kernel_timing(self.h, int(bool(on))) != 0:
+            raise _lib.VoError(-1, "vo_ba_set_kernel_timing failed")
+
+    def kernel_timing(self):
+        """{'k_ba_rot': (ms_total, launches), 'k_ba_pass': (ms_total, launches)} since timing was switched on."""
+        ms = (C.c_double * 2)(); n = (C.c_int * 2)()
+        if self.lib.vo_ba_get_kernel_timing(self.h, ms, n) != 0:
+            raise _lib.VoError(-1, "vo_ba_get_kernel_timing failed")
+        return {"k_ba_rot": (ms[0], n[0]), "k_ba_pass": (ms[1], n[1])}
+
     def run_device(self, poses, points, uv, K, r, norm, Hpp, bp, Hll, bl, Hpl, stream=None):
         """Every argument except K is a device address (int), e.g. torch.Tensor.data_ptr(); any output may be 0 to skip it."""
         K = np.ascontiguousarray(K, np.float64).reshape(3, 3)

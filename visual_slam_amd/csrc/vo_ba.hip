@@ -38,6 +38,10 @@ struct vo_ba_plan {
     double* d_work = nullptr;                                // staging for the host entry point
     size_t work_bytes = 0;
     hipStream_t stream = nullptr;
+    bool timing = false;                                     // vo_ba_set_kernel_timing
+    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    double t_ms[2] = {0, 0};
+    int t_n[2] = {0, 0};
 };
 
 struct BaK { double fx, fy, cx, cy; };
@@ -436,6 +440,7 @@ static void ba_free(vo_ba_plan* p) {
     (void)hipFree(p->d_obs_pose); (void)hipFree(p->d_obs_point); (void)hipFree(p->d_pose_start); (void)hipFree(p->d_pose_obs); (void)hipFree(p->d_pose_pt);
     (void)hipFree(p->d_point_start); (void)hipFree(p->d_point_obs); (void)hipFree(p->d_point_pose); (void)hipFree(p->d_tab); (void)hipFree(p->d_work);
     (void)hipFree(p->d_blk_start); (void)hipFree(p->d_empty);
+    for (hipEvent_t e : p->ev) if (e) (void)hipEventDestroy(e);
     if (p->stream) (void)hipStreamDestroy(p->stream);
     delete p;
 }
@@ -509,6 +514,23 @@ extern "C" int vo_ba_plan_create(int device, int P, int N, int M, const int32_t*
 
 extern "C" void vo_ba_plan_destroy(vo_ba_plan* p) { ba_free(p); }
 
+extern "C" int vo_ba_set_kernel_timing(vo_ba_plan* p, int on) {
+    if (!p) return VO_ERR_INVALID;
+    if (hipSetDevice(p->device) != hipSuccess) return VO_ERR_HIP;
+    if (on && !p->ev[0])
+        for (int i = 0; i < 3; i++)
+            if (hipEventCreate(&p->ev[i]) != hipSuccess) return VO_ERR_HIP;
+    p->timing = on != 0;
+    if (on) { p->t_ms[0] = p->t_ms[1] = 0; p->t_n[0] = p->t_n[1] = 0; }
+    return VO_OK;
+}
+
+extern "C" int vo_ba_get_kernel_timing(vo_ba_plan* p, double ms[2], int launches[2]) {
+    if (!p || !ms || !launches) return VO_ERR_INVALID;
+    for (int i = 0; i < 2; i++) { ms[i] = p->t_ms[i]; launches[i] = p->t_n[i]; }
+    return VO_OK;
+}
+
 extern "C" int vo_ba_pass_device(vo_ba_plan* p, const double* poses, const double* points, const double* uv, const double K[9], double* r2,
                                  double* nrm, double* Hpp, double* bp, double* Hll, double* bl, double* Hpl, void* stream) {
     if (!p || !poses || !points || !K || (p->M > 0 && !uv)) return VO_ERR_INVALID;
@@ -519,7 +541,9 @@ extern "C" int vo_ba_pass_device(vo_ba_plan* p, const double* poses, const doubl
     if ((((uintptr_t)uv | (uintptr_t)r2 | (uintptr_t)Hpl) & 15) != 0) return VO_ERR_INVALID;
     const bool fuse = p->fuse_points && (Hll || bl);
     const int n_empty = fuse ? p->n_empty : 0;
+    if (p->timing) (void)hipEventRecord(p->ev[0], st);
     hipLaunchKernelGGL(k_ba_rot, dim3((std::max(p->P, n_empty) + 255) / 256), dim3(256), 0, st, p->P, poses, p->d_tab, n_empty, p->d_empty, Hll, bl);
+    if (p->timing) (void)hipEventRecord(p->ev[1], st);
     BaArgs a;
     a.P = p->P; a.N = p->N; a.M = p->M;
     a.n_pose_blk = (Hpp || bp) ? (p->P + BA_PPW - 1) / BA_PPW : 0;
@@ -533,6 +557,13 @@ extern "C" int vo_ba_pass_device(vo_ba_plan* p, const double* poses, const doubl
     const int grid = a.n_pose_blk + a.n_point_blk + n_obs_blk;
     if (grid > 0) hipLaunchKernelGGL(k_ba_pass, dim3(grid), dim3(256), 0, st, a);
     if (hipGetLastError() != hipSuccess) return VO_ERR_HIP;
+    if (p->timing) {
+        if (hipEventRecord(p->ev[2], st) != hipSuccess || hipEventSynchronize(p->ev[2]) != hipSuccess) return VO_ERR_HIP;
+        float m0 = 0, m1 = 0;
+        if (hipEventElapsedTime(&m0, p->ev[0], p->ev[1]) != hipSuccess || hipEventElapsedTime(&m1, p->ev[1], p->ev[2]) != hipSuccess) return VO_ERR_HIP;
+        p->t_ms[0] += m0; p->t_n[0]++;
+        if (grid > 0) { p->t_ms[1] += m1; p->t_n[1]++; }
+    }
     if (!stream && hipStreamSynchronize(st) != hipSuccess) return VO_ERR_HIP;
     return VO_OK;
 }
