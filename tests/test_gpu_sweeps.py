@@ -141,6 +141,39 @@ def test_frame_size_sweep_against_the_oracle(oracle, kitti02, kitti09):
     assert total > 20000
 
 
+def test_batch_contexts_on_odd_sizes_against_the_oracle(oracle, kitti02):
+    """Batch contexts (several lanes; the blur there only computes the tiles a descriptor patch reaches, and the pair records come
+    from the multi-lane path) on odd frame sizes: every pair record against the oracle's -- keypoint, match and inlier counts
+    exact, which they can only be if every sampled blurred pixel is right -- on synthetic frames and on crops of a real
+    frame with large keypoint-free regions (most blur tiles skipped)."""
+    from visual_slam_amd import _lib, synth
+    K = synth.K_KITTI02
+    cases = []
+    for k, (w, h) in enumerate([(333, 201), (641, 129), (1023, 257), (450, 376)]):
+        a = np.stack([np.ascontiguousarray(synth.frame_a(np.random.default_rng(500 + 10 * k + j), max(w, 256), max(h, 256))[:h, :w]) for j in range(5)])
+        b = np.roll(a, 3, axis=2)
+        cases.append((a, b))
+    g = kitti02[0]
+    flat = g.copy(); flat[:, 400:900] = 90; flat[:150] = 120            # keypoints only in two corners of the frame
+    real = np.stack([flat[y0:y0 + 300, x0:x0 + 1100] for (x0, y0) in [(0, 0), (64, 40), (100, 76), (141, 33), (17, 5)]])
+    cases.append((np.ascontiguousarray(real), np.ascontiguousarray(np.roll(real, 2, axis=2))))
+    for a, b in cases:
+        n, h, w = a.shape
+        c = _lib.Context(max_w=w, max_h=h, chunk_pairs=2, max_pairs=n, nfeatures=1500)
+        try:
+            res = c.pairs_run(a, b, K)
+        finally:
+            c.close()
+        with ThreadPoolExecutor(_threads()) as ex:
+            ref = list(ex.map(lambda i: oracle.pair_run(a[i], b[i], K, p=oracle.default_params(nfeatures=1500)), range(n)))
+        for i, (rc, T, counts) in enumerate(ref):
+            r = res[i]
+            assert rc == r["status"], (w, h, i, rc, r["status"])
+            assert [r["n_kp1"], r["n_kp2"], r["n_match"], r["n_inlier"]] == counts.tolist(), (w, h, i)
+            if rc == 0:
+                assert np.abs(T - r["T"]).max() < 1e-6, (w, h, i)
+
+
 def test_kitti09_pair_pose_with_its_own_intrinsics(oracle, kitti09):
     """Sequence 09 has its own calibration (assets/test_imgs/09/calib.txt:1: fx 707.0912, 1226x370), hence its own RANSAC
     threshold (thr^2 = 2.0000882e-06): get_matches -> get_pose on frames 0, 1 against the oracle, and against the
