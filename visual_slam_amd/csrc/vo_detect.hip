@@ -1368,6 +1368,7 @@ __global__ __launch_bounds__(256) void k_blur(const Geom* __restrict__ g, FrameS
 #define RB_DW 11                      // dwords per patch row (39 B + up to 3 B of alignment slack)
 #define RB_PITCH 48
 #define RB_LOADS ((RB_ROWS * RB_DW + 63) / 64)   // 7 dwords per lane
+static_assert(64 * (RB_LOADS - 1) <= RB_ROWS * RB_DW, "all but a lane's last dword lie inside the patch");
 __global__ __launch_bounds__(256) void k_rbrief(const Geom* __restrict__ g, const uint8_t* __restrict__ blur, const signed char* __restrict__ pat_g,
                                                 const int* __restrict__ nkp, const vo_keypoint* __restrict__ kps,
                                                 const uint32_t* __restrict__ kplvl, uint8_t* __restrict__ desc, int nbx, int nframes) {
@@ -1435,7 +1436,8 @@ __global__ __launch_bounds__(256) void k_rbrief(const Geom* __restrict__ g, cons
         const uint8_t* base = fblur + s_ofs[lvl] + (long)(UNPACK_Y(kl) - RB_R) * pitch + (x0 - ax);
 #pragma unroll
         for (int t = 0; t < RB_LOADS; t++)
-            if (l_src[t] >= 0) regs[t] = *reinterpret_cast<const uint32_t*>(base + (__umul24((uint32_t)(l_src[t] >> 8), (uint32_t)pitch) + 4u * (uint32_t)(l_src[t] & 0xFF)));
+            if (t < RB_LOADS - 1 || l_src[t] >= 0)   // only the last of a lane's dwords can lie beyond the patch (64 t + lane < 429 for t < 6)
+                regs[t] = *reinterpret_cast<const uint32_t*>(base + (__umul24((uint32_t)(l_src[t] >> 8), (uint32_t)pitch) + 4u * (uint32_t)(l_src[t] & 0xFF)));
     };
     const int nmine = (min(n - k0, RB_KPB) - wave + 3) >> 2;   // keypoints of this wavefront
     if (nmine > 0) fetch(0, cur_ax);
@@ -1444,7 +1446,7 @@ __global__ __launch_bounds__(256) void k_rbrief(const Geom* __restrict__ g, cons
         const int ax = cur_ax;
 #pragma unroll
         for (int t = 0; t < RB_LOADS; t++)
-            if (l_src[t] >= 0) *reinterpret_cast<uint32_t*>(mypatch + l_dst[t]) = regs[t];
+            if (t < RB_LOADS - 1 || l_src[t] >= 0) *reinterpret_cast<uint32_t*>(mypatch + l_dst[t]) = regs[t];
         if (i + 1 < nmine) fetch(i + 1, cur_ax);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
