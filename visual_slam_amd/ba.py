@@ -119,6 +119,52 @@ class BAPlan:
             raise _lib.VoError(rc, "vo_ba_pass_device failed")
 
 
+def schur_step(out, obs_pose, obs_point, lam=0.0, fixed_poses=()):
+    """One damped Gauss-Newton (Levenberg-Marquardt) step from the blocks a pass returns: the caller side of
+    /root/reference/vo.py:112-135, where the reference lets scipy `least_squares` differentiate numerically.
+    Solves  [Hpp + lam D  Hpl; Hpl^T  Hll + lam D] [dp; dl] = -[bp; bl]  by the Schur complement on the points (each Hll block is
+    3 x 3): S dp = -bp + sum Hpl Hll^-1 bl, then dl = Hll^-1 (-bl - Hpl^T dp).  Host numpy, dense reduced camera system
+    (6P x 6P): meant for the reference's problem sizes (a handful of poses) and as a check that the blocks ARE the normal
+    equations -- a large problem wants a sparse / device solver on the same blocks.  `fixed_poses`: indices held at zero
+    update (gauge).  Returns (dp [P,6], dl [N,3]); poses and points are updated by adding them."""
+    Hpp = np.array(out["Hpp"], np.float64); bp = np.asarray(out["bp"], np.float64)
+    Hll = np.array(out["Hll"], np.float64); bl = np.asarray(out["bl"], np.float64); Hpl = np.asarray(out["Hpl"], np.float64)
+    P, N = len(Hpp), len(Hll)
+    if lam > 0:
+        for j in range(P):
+            Hpp[j] += lam * np.diag(np.maximum(np.diag(Hpp[j]), 1e-12))
+        for i in range(N):
+            Hll[i] += lam * np.diag(np.maximum(np.diag(Hll[i]), 1e-12))
+    seen = np.zeros(N, bool); seen[np.asarray(obs_point)] = True
+    Hinv = np.zeros_like(Hll)
+    Hinv[seen] = np.linalg.inv(Hll[seen])
+    S = np.zeros((6 * P, 6 * P)); g = -bp.reshape(-1).copy()
+    for j in range(P):
+        S[6 * j:6 * j + 6, 6 * j:6 * j + 6] = Hpp[j]
+    by_point = {}
+    for o, (j, i) in enumerate(zip(np.asarray(obs_pose), np.asarray(obs_point))):
+        by_point.setdefault(int(i), []).append((int(j), o))
+    for i, lst in by_point.items():
+        for j, o in lst:
+            WH = Hpl[o] @ Hinv[i]                                    # 6 x 3
+            g[6 * j:6 * j + 6] += WH @ bl[i]
+            for k, o2 in lst:
+                S[6 * j:6 * j + 6, 6 * k:6 * k + 6] -= WH @ Hpl[o2].T
+    free = np.ones(6 * P, bool)
+    for j in fixed_poses:
+        free[6 * j:6 * j + 6] = False
+    dp = np.zeros(6 * P)
+    dp[free] = np.linalg.solve(S[np.ix_(free, free)], g[free])
+    dp = dp.reshape(P, 6)
+    dl = np.zeros((N, 3))
+    for i, lst in by_point.items():
+        rhs = -bl[i].copy()
+        for j, o in lst:
+            rhs -= Hpl[o].T @ dp[j]
+        dl[i] = Hinv[i] @ rhs
+    return dp, dl
+
+
 def allreduce_pose_blocks(Hpp, bp, force=False):
     """Sum the pose blocks of every rank (observations sharded by point): ONE all_reduce of the
     packed [P,42] float64 buffer (36 J^T J + 6 J^T r per pose; 336 KB at P = 1000) -- the only
