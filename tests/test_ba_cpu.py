@@ -79,3 +79,39 @@ def test_sharded_pose_blocks_allreduce_gloo():
     assert sum(g[3] for g in got) == len(pr["obs_pose"])
     for _, H, b, _ in got:
         assert np.allclose(H, full["Hpp"], rtol=1e-12, atol=1e-9) and np.allclose(b, full["bp"], rtol=1e-12, atol=1e-9)
+
+
+def test_schur_step_solves_the_normal_equations():
+    """ba.schur_step (host logic of the BA caller side, vo.py:112-135) on the numpy oracle's blocks: the step equals the solution
+    of the full damped normal equations assembled densely, and a few steps reach the noise floor."""
+    P, N, noise = 4, 60, 0.2
+    pr = ba.synth_problem(n_poses=P, n_points=N, obs_per_point=3, seed=4, noise=noise)
+    rng = np.random.default_rng(1)
+    poses = pr["poses"].copy(); points = pr["points"] + rng.normal(0, 0.1, pr["points"].shape)
+    poses[1:, 3:] += rng.normal(0, 0.03, (P - 1, 3))
+    run = lambda ps, xs: BO.ba_pass(ps, xs, pr["obs_pose"], pr["obs_point"], pr["uv"], pr["K"])
+    out = run(poses, points)
+    lam = 1e-2
+    dp, dl = ba.schur_step(out, pr["obs_pose"], pr["obs_point"], lam, fixed_poses=(0,))
+    # dense reference: unknowns = poses 1..P-1 and all points
+    n = 6 * P + 3 * N
+    H = np.zeros((n, n)); g = np.zeros(n)
+    for j in range(P):
+        H[6 * j:6 * j + 6, 6 * j:6 * j + 6] = out["Hpp"][j]; g[6 * j:6 * j + 6] = -out["bp"][j]
+    for i in range(N):
+        a = 6 * P + 3 * i
+        H[a:a + 3, a:a + 3] = out["Hll"][i]; g[a:a + 3] = -out["bl"][i]
+    for o, (j, i) in enumerate(zip(pr["obs_pose"], pr["obs_point"])):
+        a = 6 * P + 3 * i
+        H[6 * j:6 * j + 6, a:a + 3] += out["Hpl"][o]; H[a:a + 3, 6 * j:6 * j + 6] += out["Hpl"][o].T
+    H += lam * np.diag(np.maximum(np.diag(H), 1e-12))
+    free = np.ones(n, bool); free[:6] = False
+    x = np.zeros(n); x[free] = np.linalg.solve(H[np.ix_(free, free)], g[free])
+    assert np.allclose(dp.reshape(-1), x[:6 * P], rtol=1e-7, atol=1e-10) and np.allclose(dl.reshape(-1), x[6 * P:], rtol=1e-7, atol=1e-10)
+    cost = lambda o: float((o["r"] ** 2).sum())
+    c = [cost(out)]
+    for _ in range(8):
+        dp, dl = ba.schur_step(out, pr["obs_pose"], pr["obs_point"], 1e-4, fixed_poses=(0,))
+        poses, points = poses + dp, points + dl
+        out = run(poses, points); c.append(cost(out))
+    assert np.sqrt(c[-1] / (2 * len(pr["uv"]))) < 1.2 * noise < np.sqrt(c[0] / (2 * len(pr["uv"])))
